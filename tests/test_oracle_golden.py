@@ -1,0 +1,236 @@
+"""Pins the numpy oracle (oracle/spectre_oracle.py) to golden vectors produced by executing the
+reference's own modules (tests/golden/make_golden.py).  float64 on both sides -> tight tolerances."""
+import numpy as np
+import pytest
+
+from conftest import load_model_fixture
+from oracle import spectre_oracle as O
+
+RT, AT = 1e-9, 1e-10
+
+
+def close(a, b, rtol=RT, atol=AT):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+def sl_params(g, pre):
+    return dict(weight=g[pre + "local_head.0.weight"].astype(np.float64),
+                bias=g[pre + "local_head.0.bias"].astype(np.float64),
+                ln_weight=g[pre + "local_head.1.weight"].astype(np.float64),
+                ln_bias=g[pre + "local_head.1.bias"].astype(np.float64))
+
+
+def check_sl_grads(grads, g, pre):
+    close(grads["weight"], g[pre + "local_head.0.weight"])
+    close(grads["bias"], g[pre + "local_head.0.bias"])
+    close(grads["ln_weight"], g[pre + "local_head.1.weight"])
+    close(grads["ln_bias"], g[pre + "local_head.1.bias"])
+
+
+@pytest.mark.parametrize("name", ["sl_equal", "sl_down_exact", "sl_down_overlap", "sl_up", "sl_head2d"])
+def test_spectre_linear(golden_ops, name):
+    g = golden_ops
+    p = sl_params(g, f"{name}.sd.")
+    y, cache = O.spectre_linear_fwd(g[f"{name}.x"], p)
+    close(y, g[f"{name}.y"])
+    dx, grads = O.spectre_linear_bwd(g[f"{name}.dy"], p, cache)
+    close(dx, g[f"{name}.dx"])
+    check_sl_grads(grads, g, f"{name}.grad.")
+
+
+def test_pool_windows_match_survey():
+    # SURVEY 8a-3 probe: 8192->512 exact 16-means; 768->512 overlapping 2-windows; 512->768 sizes 1-2; 512->100 sizes 6-7
+    s, e = O.adaptive_pool_windows(8192, 512)
+    assert set(e - s) == {16}
+    s, e = O.adaptive_pool_windows(768, 512)
+    assert set(e - s) == {2}
+    s, e = O.adaptive_pool_windows(512, 768)
+    assert set(e - s) == {1, 2}
+    s, e = O.adaptive_pool_windows(512, 100)
+    assert set(e - s) == {6, 7}
+
+
+def test_mh_permut_mix(golden_ops):
+    g = golden_ops
+    p = dict(perms=g["permut.sd.perms"], signs=g["permut.sd.signs"].astype(np.float64),
+             linear=sl_params(g, "permut.sd.linear."))
+    close(O.permut_gather_fwd(g["permut.x"], p["perms"], p["signs"]), g["permut.gathered"])
+    y, cache = O.mh_permut_mix_fwd(g["permut.x"], p)
+    close(y, g["permut.y"])
+    dx, grads = O.mh_permut_mix_bwd(g["permut.dy"], p, cache)
+    close(dx, g["permut.dx"])
+    check_sl_grads(grads["linear"], g, "permut.grad.linear.")
+
+
+def test_permut_raw_reshape_closed_form(golden_ops):
+    """element (t,c) of the reshaped tensor is the gather at flat f=t*E*H+c, h=f//d, j=f%d."""
+    g = golden_ops
+    x = g["permut.x"]
+    B, N, E = x.shape
+    perms, signs = g["permut.sd.perms"], g["permut.sd.signs"]
+    H, d = perms.shape
+    got = g["permut.gathered"]
+    xf = x.reshape(B, d)
+    for t in range(N):
+        for c in range(0, E * H, 5):
+            f = t * E * H + c
+            h, j = divmod(f, d)
+            assert got[1, t, c] == xf[1, perms[h, j]] * signs[0, h, j]
+
+
+def test_spectral_patch_embed(golden_ops):
+    g = golden_ops
+    f = lambda k: g["spe.sd." + k].astype(np.float64)
+    p = dict(freq_weight_h=f("freq_weight_h"), freq_weight_w=f("freq_weight_w"), proj_weight=f("proj.weight"),
+             proj_bias=f("proj.bias"), cls_token=f("cls_token"), position_embeddings=f("position_embeddings"))
+    y, cache = O.spectral_patch_embed_fwd(g["spe.x"], p, 4)
+    close(y, g["spe.y"])
+    grads = O.spectral_patch_embed_bwd(g["spe.dy"], p, 4, cache)
+    for k_o, k_g in [("freq_weight_h", "freq_weight_h"), ("freq_weight_w", "freq_weight_w"),
+                     ("proj_weight", "proj.weight"), ("proj_bias", "proj.bias"), ("cls_token", "cls_token"),
+                     ("position_embeddings", "position_embeddings")]:
+        close(grads[k_o], g["spe.grad." + k_g])
+
+
+def test_conv_patch_embed(golden_ops):
+    g = golden_ops
+    f = lambda k: g["pe.sd." + k].astype(np.float64)
+    p = dict(conv_weight=f("patcher.0.weight"), conv_bias=f("patcher.0.bias"), cls_token=f("cls_token"),
+             position_embeddings=f("position_embeddings"))
+    y, feat = O.conv_patch_embed_fwd(g["pe.x"], p, 4)
+    close(y, g["pe.y"])
+    grads = O.conv_patch_embed_bwd(g["pe.dy"], p, 4, feat)
+    close(grads["conv_weight"], g["pe.grad.patcher.0.weight"])
+    close(grads["conv_bias"], g["pe.grad.patcher.0.bias"])
+    close(grads["cls_token"], g["pe.grad.cls_token"])
+    close(grads["position_embeddings"], g["pe.grad.position_embeddings"])
+
+
+def test_fft_module_and_fnet(golden_ops):
+    g = golden_ops
+    close(O.fft_module_fwd(g["fftmod.x"]), g["fftmod.y"])
+    close(O.fft_module_bwd(g["fftmod.dy"], g["fftmod.x"].shape[-1]), g["fftmod.dx"])
+    close(O.fnet_mix_fwd(g["fnet.x"]), g["fnet.y"])
+    close(O.fnet_mix_bwd(g["fnet.dy"]), g["fnet.dx"])
+    close(O.fnet_mix_fwd(g["fnet65.x"]), g["fnet65.y"], rtol=1e-8, atol=1e-9)
+
+
+def test_fnet_symmetry_property():
+    """y[m,k] == y[(N-m)%N,(D-k)%D] for real input -- the property the HIP kernel exploits."""
+    x = np.random.default_rng(0).standard_normal((2, 65, 32))
+    y = O.fnet_mix_fwd(x)
+    m = (-np.arange(65)) % 65
+    k = (-np.arange(32)) % 32
+    close(y, y[:, m][:, :, k], rtol=1e-8, atol=1e-9)
+
+
+def test_encoder_layer(golden_ops):
+    g = golden_ops
+    sd = {k[len("layer.sd."):]: v for k, v in g.items() if k.startswith("layer.sd.")}
+    f = lambda k: sd[k].astype(np.float64)
+    lp = dict(mix_layer=dict(perms=sd["mix_layer.perms"], signs=f("mix_layer.signs"),
+                             linear=sl_params(g, "layer.sd.mix_layer.linear.")),
+              linear1=sl_params(g, "layer.sd.linear1."), linear3=sl_params(g, "layer.sd.linear3."),
+              norm1_weight=f("norm1.weight"), norm1_bias=f("norm1.bias"),
+              norm2_weight=f("norm2.weight"), norm2_bias=f("norm2.bias"))
+    y, cache = O.encoder_layer_fwd(g["layer.x"], lp, "permut")
+    close(y, g["layer.y"])
+    dx, grads = O.encoder_layer_bwd(g["layer.dy"], lp, cache, "permut")
+    close(dx, g["layer.dx"])
+    check_sl_grads(grads["linear1"], g, "layer.grad.linear1.")
+    check_sl_grads(grads["linear3"], g, "layer.grad.linear3.")
+    check_sl_grads(grads["mix_layer"]["linear"], g, "layer.grad.mix_layer.linear.")
+    close(grads["norm1_weight"], g["layer.grad.norm1.weight"])
+    close(grads["norm2_bias"], g["layer.grad.norm2.bias"])
+
+
+def tel_params(g, pre):
+    f = lambda k: g[pre + k].astype(np.float64)
+    return dict(attn=dict(in_proj_weight=f("self_attn.in_proj_weight"), in_proj_bias=f("self_attn.in_proj_bias"),
+                          out_proj_weight=f("self_attn.out_proj.weight"), out_proj_bias=f("self_attn.out_proj.bias")),
+                linear1_weight=f("linear1.weight"), linear1_bias=f("linear1.bias"),
+                linear2_weight=f("linear2.weight"), linear2_bias=f("linear2.bias"),
+                norm1_weight=f("norm1.weight"), norm1_bias=f("norm1.bias"),
+                norm2_weight=f("norm2.weight"), norm2_bias=f("norm2.bias"))
+
+
+def test_transformer_layer_batch_axis_quirk(golden_ops):
+    """vit.py:30-36: batch_first=False fed (B,N,E) => attention across the batch axis."""
+    g = golden_ops
+    p = tel_params(g, "tel.sd.")
+    y, cache = O.transformer_layer_fwd(g["tel.x"], p, 4, batch_first=False)
+    close(y, g["tel.y"])
+    dx, grads = O.transformer_layer_bwd(g["tel.dy"], p, 4, cache, batch_first=False)
+    close(dx, g["tel.dx"])
+    close(grads["attn"]["in_proj_weight"], g["tel.grad.self_attn.in_proj_weight"])
+    close(grads["attn"]["out_proj_bias"], g["tel.grad.self_attn.out_proj.bias"])
+    close(grads["linear1_weight"], g["tel.grad.linear1.weight"])
+    close(grads["linear2_weight"], g["tel.grad.linear2.weight"])
+    close(grads["norm1_weight"], g["tel.grad.norm1.weight"])
+    # the sane batch_first=True mode must differ (it is the build's own extension)
+    y2, _ = O.transformer_layer_fwd(g["tel.x"], p, 4, batch_first=True)
+    assert np.abs(y2 - g["tel.y"]).max() > 1e-3
+
+
+def test_baseline_vit_forward(golden_ops):
+    g = golden_ops
+    f = lambda k: g["vit.sd." + k].astype(np.float64)
+    p = dict(conv_weight=f("embeddings_block.patcher.0.weight"), conv_bias=f("embeddings_block.patcher.0.bias"),
+             cls_token=f("embeddings_block.cls_token"), position_embeddings=f("embeddings_block.position_embeddings"))
+    x, _ = O.conv_patch_embed_fwd(g["vit.x"], p, 4)
+    for i in range(2):
+        x, _ = O.transformer_layer_fwd(x, tel_params(g, f"vit.sd.encoder_blocks.layers.{i}."), 4, batch_first=False)
+    cls = x[:, 0, :]
+    close(cls, g["vit.cls"])
+    close(cls @ f("mlp_head.0.weight").T + f("mlp_head.0.bias"), g["vit.logits"])
+    # logits identical for every image
+    assert np.abs(g["vit.logits"] - g["vit.logits"][0]).max() < 1e-12
+
+
+@pytest.mark.parametrize("name", ["model_tiny_mnist", "model_small_cut"])
+def test_whole_model_train_step(name):
+    d, cfg = load_model_fixture(name)
+    sd = {k[3:]: v for k, v in d.items() if k.startswith("sd.")}
+    loss, logits, cls, grads = O.train_step(d["img"], d["labels"], sd, cfg["num_encoders"], cfg["patch_size"],
+                                            "permut", np.float64)
+    close(logits, d["logits"], rtol=1e-8, atol=1e-9)
+    close(cls, d["cls"], rtol=1e-8, atol=1e-9)
+    close(loss, d["loss"], rtol=1e-9)
+    n = 0
+    for k, v in d.items():
+        if k.startswith("grad."):
+            close(grads[k[5:]], v, rtol=1e-7, atol=1e-9)
+            n += 1
+    assert n == len(grads)
+    # one AdamW step (train.py:199-201)
+    for k, gk in grads.items():
+        p0 = sd[k].astype(np.float64)
+        p1, _, _ = O.adamw_step(p0, gk, np.zeros_like(p0), np.zeros_like(p0), 1)
+        close(p1, d["after." + k], rtol=1e-7, atol=1e-9)
+
+
+def test_haar_dwt_orthonormal_roundtrip():
+    """PARITY UNPINNED row: pinned to the definition -- orthonormal, adjoint == inverse."""
+    rng = np.random.default_rng(1)
+    for shape, axis, J in [((2, 65, 32), -2, 1), ((2, 65, 32), -2, 3), ((2, 5, 64), -1, 1), ((2, 5, 64), -1, 6)]:
+        x = rng.standard_normal(shape)
+        y = O.haar_dwt_fwd(x, axis, J)
+        assert y.shape == x.shape
+        close((y ** 2).sum(), (x ** 2).sum(), rtol=1e-12)
+        close(O.haar_dwt_bwd(y, axis, J), x, rtol=1e-12, atol=1e-12)
+    # first full pair follows pywt 'haar': a=(x0+x1)/sqrt2, d=(x0-x1)/sqrt2, bands = [a | d]
+    x = np.array([[1.0, 3.0, 2.0, 6.0]])
+    close(O.haar_dwt_fwd(x, -1, 1), np.array([[4.0, 8.0, -2.0, -4.0]]) / np.sqrt(2))
+
+
+def test_distill_loss_gradient_numeric():
+    rng = np.random.default_rng(2)
+    s, t = rng.standard_normal((3, 7)), rng.standard_normal((3, 7))
+    lab = np.array([1, 0, 6])
+    loss, d, _, _ = O.distill_loss_fwd_bwd(s, t, lab)
+    num = np.zeros_like(s)
+    for i in np.ndindex(*s.shape):
+        sp = s.copy(); sp[i] += 1e-6
+        sm = s.copy(); sm[i] -= 1e-6
+        num[i] = (O.distill_loss_fwd_bwd(sp, t, lab)[0] - O.distill_loss_fwd_bwd(sm, t, lab)[0]) / 2e-6
+    close(d, num, rtol=1e-5, atol=1e-8)
