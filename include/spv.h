@@ -1,0 +1,167 @@
+/*
+ * spv.h -- C-ABI of libspv_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the
+ * Spectre-ViT encoder training step.
+ *
+ * This is the drop-in boundary below the reference's nn.Module surface.  The
+ * reference has no native layer at all: every entry point here replaces a chain of stock ATen ops
+ * issued by a reference module, cited per function as  <reference file>:<lines>.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed for the duration of the call (nothing is kept,
+ *     nothing is allocated); tensors are dense row-major unless a leading dimension is given;
+ *   - `dtype` arguments: SPV_F32 (0) or SPV_BF16 (1); statistics, parameters, gradients of
+ *     parameters and all accumulation are fp32 regardless;
+ *   - `stream` is the hipStream_t to launch on (the caller's current stream); calls never
+ *     synchronise and are hipGraph-capturable;
+ *   - return value: 0 = ok, non-zero = error (bad shape / alignment / launch failure); the
+ *     message is available from spv_last_error() (thread local).
+ */
+#ifndef SPV_H
+#define SPV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPV_F32 0
+#define SPV_BF16 1
+
+#define SPV_ABI_VERSION 1
+
+int spv_version(void);
+const char* spv_last_error(void);
+
+/* ---- precision plumbing -------------------------------------------------------------------
+ * torch.autocast's weight cast (spectre_vit/repl/train.py:219) as one kernel; `transpose` also
+ * writes the [cols][rows] copy used by the data-gradient GEMM. */
+int spv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, void* stream);
+/* dst[c][r] = src[map(r)][c]; dst leading dimension ld >= rows (pad zero filled).  rows_per_group > 0 reads the
+ * grouped source row (r / rows_per_group) * group_stride + row_offset + r % rows_per_group (e.g. the token rows
+ * of every image without its CLS row). */
+int spv_cast_transpose(const void* src, int src_dtype, void* dst, int dst_dtype, int rows, int cols, int ld,
+                       int rows_per_group, int group_stride, int row_offset, void* stream);
+
+/* ---- dense contraction: C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ C) ------------------------
+ * nn.Linear inside SpectreLinear (spectre_vit/models/spectre/layers.py:85-86,100), its data and
+ * weight gradients, and the patch projection (spectre.py:148).  MFMA: v_mfma_f32_32x32x16_bf16
+ * (bf16 in) or v_mfma_f32_32x32x2_f32 (exact fp32 in); fp32 accumulate.
+ * K, lda, ldb must be multiples of 16 bytes / sizeof(in element); A,B 16-byte aligned.
+ * splits > 1: split-K over `splits` slices, fp32 partial slabs in `workspace`
+ * (>= splits*M*N*4 bytes), reduced by a second kernel (deterministic). */
+int spv_gemm_nt(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda,
+                int ldb, int ldc, int in_dtype, int out_dtype, int accumulate, int splits,
+                void* workspace, void* stream);
+/* Same contraction, output row m written to row (m / rows_per_group) * group_stride + row_offset + m % rows_per_group
+ * and bias2d[m % rows_per_group][N] added: the patch projection writing straight into the token tensor
+ * (position embedding + bias as bias2d, every image's CLS row skipped) -- spectre.py:148-152. */
+int spv_gemm_nt_grouped_rows(const void* A, const void* B, const float* bias, const float* bias2d, void* C, int M,
+                             int N, int K, int lda, int ldb, int ldc, int in_dtype, int out_dtype,
+                             int rows_per_group, int group_stride, int row_offset, void* stream);
+
+/* ---- SpectreLinear tail: out = dropout(GELU_erf(LayerNorm(h)) + adaptive_avg_pool(x)) ---------
+ * spectre_vit/models/spectre/layers.py:85-101 (LN eps 1e-5, nn.GELU exact, AdaptiveAvgPool1d over the
+ * channel axis; identity skip when k_in == n) + the nn.Dropout that follows it in
+ * spectre.py:70-73.  h: [rows,n] pre-norm linear output, x: [rows,k_in] the layer input.
+ * Saves mean/rstd [rows] fp32 for the backward.  p_drop == 0 disables dropout. */
+int spv_spectre_tail_fwd(const void* h, const void* x, const float* gamma, const float* beta, void* out,
+                         float* mean, float* rstd, int rows, int n, int k_in, int dtype, int out_dtype,
+                         float p_drop, uint64_t seed, void* stream);
+
+/* Backward of the tail.  dout [rows,n] (dout_dtype) -> dh [rows,n] (dtype), dx_pool [rows,k_in] (dtype; the
+ * transposed pooling of the masked dout, to which the caller accumulates dh.W), and the fp32
+ * column sums dgamma/dbeta/dbias [n].  `partials` is fp32 scratch of spv_rowop_partial_floats(n)
+ * floats. */
+int spv_spectre_tail_bwd(const void* dout, const void* h, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, void* dh, void* dx_pool, float* dgamma,
+                         float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype,
+                         int dout_dtype, float p_drop, uint64_t seed, void* stream);
+int64_t spv_rowop_partial_floats(int n);
+
+/* ---- residual + LayerNorm ------------------------------------------------------------------------
+ * mode 0: out = LN(a) + b      norm1(mix(x)) + x   spectre_vit/models/spectre/spectre.py:66
+ * mode 1: out = LN(a + b)      norm2(x + ff(x))    spectre.py:67
+ * backward returns d(LN input) in `din` and dgamma/dbeta; the residual gradient of mode 0's `b`
+ * is dout itself. */
+int spv_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const float* beta, void* out,
+                          float* mean, float* rstd, int rows, int n, int mode, int dtype, void* stream);
+int spv_add_layernorm_bwd(const void* dout, const void* a, const void* b, const float* mean,
+                          const float* rstd, const float* gamma, void* din, float* dgamma, float* dbeta,
+                          float* partials, int rows, int n, int mode, int dtype, void* stream);
+
+/* ---- MHPermutMix gather: g[b,f] = x[b, perm[f]] * sign[f], f in [0, heads*d) ------------------------
+ * spectre_vit/models/spectre/layers.py:68-72 (advanced-index gather, sign multiply, raw reshape to
+ * (B, tokens, embed*heads) -- the reshape is free: g is written flat).  `idx` is the packed table
+ * from spv_permut_pack: bit31 = sign (1 => -1), bits 0..30 = source index.
+ * backward: dx[b,i] = sum_h sign[h,inv_h(i)] * dg[b,h,inv_h(i)] (each perms[h] is a permutation:
+ * no atomics, head by head in LDS). */
+/* idx: uint32 [2][heads][d] -- [0] forward table (perm | sign), [1] inverse table (inverse perm | sign). */
+int spv_permut_pack(const int64_t* perms, const float* signs, uint32_t* idx, int heads, int d, void* stream);
+int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g, int batch, int heads, int d,
+                          int dtype, void* stream);
+int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* dx, int batch, int heads, int d,
+                          int dtype, void* stream);
+
+/* ---- FNet token mixer y = Re(fft2(x)) over (tokens, dim), un-normalised ------------------------------
+ * spectre_vit/models/spectre_branch/spectre_branch.py:79, repl/orthogonal_permut.py:23-28 ('fft_bare',
+ * spectre.py:31).  The operator is symmetric, so the same call is its own backward.
+ * `twiddle`: token-axis cos/sin table of spv_fnet_twiddle_floats(tokens) floats filled once by
+ * spv_fnet_make_twiddle (the caller caches it).  `workspace`: fp32 scratch of
+ * spv_fnet_workspace_floats(batch,tokens,dim) floats (0 on the LDS fast path: dim a power of two,
+ * tokens <= 79 and (tokens+3)*dim*4 <= 160 KiB). */
+int spv_fnet_mix(const void* x, void* y, const float* twiddle, int batch, int tokens, int dim, int dtype,
+                 float* workspace, void* stream);
+int64_t spv_fnet_workspace_floats(int batch, int tokens, int dim);
+int64_t spv_fnet_twiddle_floats(int tokens);
+int spv_fnet_make_twiddle(float* twiddle, int tokens, void* stream);
+
+/* FFT module: y[..,k] = sum_d x[..,d] cos(2 pi k d / D), k in [0, D/2]  (rfft(x).real)
+ * spectre_vit/modules/spectre.py:9-14.  transpose=1 computes the adjoint (the backward). */
+int spv_rfft_real(const void* x, void* y, int rows, int dim, int transpose, int dtype, void* stream);
+
+/* ---- Haar DWT mixers ('dwt_embed' along dim, 'dwt_token' along tokens) ---------------------------
+ * named in spectre_vit/models/spectre/spectre.py:33-34; only call site repl/dwt_experiments.py:56.
+ * Orthonormal pairs a=(x0+x1)/sqrt2, d=(x0-x1)/sqrt2, output [a_J | d_J | ... | d_1]; an odd trailing
+ * element passes through.  inverse=1 applies the adjoint (= inverse = the backward). */
+int spv_haar_dwt(const void* x, void* y, int batch, int tokens, int dim, int axis, int levels, int inverse,
+                 int dtype, void* scratch, void* stream);
+
+/* ---- patch embedding ---------------------------------------------------------------------------
+ * tokens[b,0,:] = cls + pos[0]; tokens[b,1+n,:] = W_full . patch(b,n) + bias + pos[1+n]
+ * where patch(b,n) is the (c,p,q)-ordered P x P pixel block.  With W_full = conv weight this is
+ * PatchEmbedding (spectre_vit/modules/patch_embeddings.py:28-43); with
+ * W_full = (proj.weight * freq_h (x) freq_w) . R, R = Re(rfft2 ortho) it is SpectralPatchEmbed
+ * (spectre_vit/models/spectre/spectre.py:124-156).  The contraction itself is spv_gemm_nt_grouped_rows;
+ * these entry points are the plumbing around it:
+ *   spv_patchify        pixel blocks -> [B*Np, ld>=K] rows (or the [K, ld>=B*Np] transpose for the weight gradient)
+ *   spv_embed_posbias   bias2d[t][e] = pos[1+t][e] + bias[e]
+ *   spv_embed_cls_rows  tokens[b,0,:] = cls + pos[0]
+ *   spv_spectral_fold / _bwd   W_full from (proj.weight, freq_h, freq_w) and the gradients back
+ *                       (scratch: embed*chans*patch*(patch/2+1) floats)
+ *   spv_dropout         y = x * mask(seed, index) / (1-p): nn.Dropout (spectre.py:154) with a counter-based
+ *                       mask that the backward regenerates (same call on the gradient). */
+int spv_patchify(const float* img, void* out, int batch, int chans, int height, int width, int patch, int ld,
+                 int transposed, int out_dtype, void* stream);
+int spv_embed_posbias(const float* pos, const float* bias, float* out, int patches, int embed, void* stream);
+int spv_embed_cls_rows(const float* cls, const float* pos, void* tokens, int batch, int tokens_per_image, int embed,
+                       int dtype, void* stream);
+int spv_spectral_fold(const float* proj_w, const float* freq_h, const float* freq_w, float* w_full, int embed,
+                      int chans, int patch, void* stream);
+int spv_spectral_fold_bwd(const float* dw_full, const float* proj_w, const float* freq_h, const float* freq_w,
+                          float* dproj_w, float* dfreq_h, float* dfreq_w, float* scratch, int embed, int chans,
+                          int patch, void* stream);
+int spv_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+
+/* ---- generic helpers used by the module mirror ------------------------------------------------------
+ * GELU (TransformerEncoderLayer MLP, vit.py:30-36), column sums (bias / position-embedding gradients;
+ * partials: >= min(rows,512)*n floats), a*x + b*y. */
+int spv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream);
+int spv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream);
+int spv_colsum(const void* x, float* out, float* partials, int rows, int n, int dtype, void* stream);
+int spv_axpby(const void* x, const void* y, void* out, float a, float b, int64_t n, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPV_H */

@@ -1,0 +1,176 @@
+"""GPU parity of whole modules / the whole model against (a) the golden vectors generated from the reference and
+(b) the numpy oracle, plus size-independent properties at the benchmark size."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_model_fixture
+from oracle import spectre_oracle as O
+from test_gpu_ops import check, dev, n64, t
+
+pytestmark = pytest.mark.gpu
+
+
+def build(cfg, sd=None, **kw):
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    m = SpectreViT(**cfg, **kw).to(dev())
+    if sd is not None:
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return m
+
+
+def test_encoder_layer_golden(golden_ops):
+    from spectre_vit.models.spectre.spectre import SpectreEncoderLayer
+    g = golden_ops
+    m = SpectreEncoderLayer(seq_length=5, d_model=16, nhead=2, dim_feedforward=24, dropout=0.0, activation="gelu").to(dev())
+    m.load_state_dict({k[len("layer.sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("layer.sd.")})
+    x = t(g["layer.x"]).requires_grad_(True)
+    y = m(x)
+    y.backward(t(g["layer.dy"]))
+    check(y, g["layer.y"], 3e-5, "y")
+    check(x.grad, g["layer.dx"], 1e-4, "dx")
+    for k, p in m.named_parameters():
+        check(p.grad, g["layer.grad." + k], 1e-4, "grad " + k)
+
+
+@pytest.mark.parametrize("name", ["model_tiny_mnist", "model_small_cut"])
+def test_model_train_step_golden(name):
+    """fp32 kernels vs the reference's own forward / CE / backward / AdamW step (identical weights and inputs)."""
+    d, cfg = load_model_fixture(name)
+    sd = {k[3:]: v for k, v in d.items() if k.startswith("sd.")}
+    m = build(cfg, sd)
+    m.train()
+    img, labels = t(d["img"]), torch.from_numpy(d["labels"]).to(dev())
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    logits, cls = m(img, return_features=True)
+    loss = torch.nn.CrossEntropyLoss()(logits, labels)
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    check(logits, d["logits"], 5e-5, "logits")
+    check(cls, d["cls"], 5e-5, "cls")
+    assert abs(loss.item() - float(d["loss"])) < 5e-5 * abs(float(d["loss"]))
+    for k, p in m.named_parameters():
+        check(p.grad, d["grad." + k], 3e-4, "grad " + k)
+    opt.step()
+    for k, p in m.named_parameters():
+        check(p, d["after." + k], 1e-5, "after-AdamW " + k)
+    with torch.no_grad():
+        check(m(img), d["logits_after"], 2e-4, "logits after step")
+
+
+@pytest.mark.parametrize("mixer,kw", [("fft", {}), ("dwt_embed", {"dwt_levels": 2}), ("dwt_token", {}), ("permut", {})])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_model_vs_oracle_mixers(mixer, kw, dtype):
+    """cut-down Small with every mixer; fp32 within 2e-4 of the float64 oracle, bf16 autocast within 6e-2."""
+    cfg = dict(img_size=16, patch_size=4, in_channels=3, num_classes=100, embed_dim=64, num_encoders=2, num_heads=4,
+               hidden_dim=96, dropout=0.0, activation="gelu")
+    torch.manual_seed(42)
+    m = build(cfg, mixer=mixer, **kw)
+    with torch.no_grad():  # non-trivial LN affines so their gradients are exercised
+        for p in m.parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    g = torch.Generator().manual_seed(1234)
+    img = torch.randn(6, 3, 16, 16, generator=g)
+    labels = torch.randint(0, 100, (6,), generator=g)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    params = O.params_from_state_dict(sd, 2, mixer, np.float64)
+    for lp in params["layers"]:
+        lp["dwt_levels"] = kw.get("dwt_levels", 1)
+    logits_ref, cls_ref, cache = O.spectre_vit_fwd(img.numpy().astype(np.float64), params, 4, mixer)
+    loss_ref, dlog = O.cross_entropy_fwd_bwd(logits_ref, labels.numpy())
+    gref = O.grads_to_state_dict(O.spectre_vit_bwd(dlog, params, 4, cache, mixer))
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        logits, cls = m(img.to(dev()), return_features=True)
+    assert logits.dtype == torch.float32
+    loss = torch.nn.CrossEntropyLoss()(logits, labels.to(dev()))
+    loss.backward()
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    check(logits, logits_ref, tol, "logits")
+    check(cls, cls_ref, tol, "cls")
+    for k, p in m.named_parameters():
+        check(p.grad, gref[k], tol * 3, "grad " + k)
+
+
+def small_cfg():
+    # configs/spectre_vit_cifar100.py:3-20 of the reference
+    return dict(img_size=32, patch_size=4, in_channels=3, num_classes=100, embed_dim=512, num_encoders=4, num_heads=16,
+                hidden_dim=768, dropout=0.0, activation="gelu")
+
+
+@pytest.mark.parametrize("mixer", ["fft", "permut"])
+def test_full_size_properties(mixer):
+    """Small/CIFAR-100 at bs 64, bf16: determinism, finite grads, and the data-parallel identity
+    grad(batch) == mean over shards of grad(shard) (no op mixes samples: SURVEY 8e)."""
+    torch.manual_seed(42)
+    m = build(small_cfg(), mixer=mixer)
+    g = torch.Generator().manual_seed(1234)
+    img = torch.randn(64, 3, 32, 32, generator=g).to(dev())
+    labels = torch.randint(0, 100, (64,), generator=g).to(dev())
+
+    def grads(x, y):
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(x)
+        torch.nn.CrossEntropyLoss()(out, y).backward()
+        return out.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    o1, g1 = grads(img, labels)
+    o2, g2 = grads(img, labels)
+    assert torch.equal(o1, o2), "forward must be run-to-run deterministic"
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g1[k], g2[k]), f"backward must be deterministic ({k})"
+    _, ga = grads(img[:32], labels[:32])
+    _, gb = grads(img[32:], labels[32:])
+    worst = 0.0
+    for k in g1:
+        mean = (ga[k] + gb[k]) / 2
+        e = (mean - g1[k]).abs().max().item() / (g1[k].abs().max().item() + 1e-30)
+        worst = max(worst, e)
+    assert worst < 2e-2, f"shard-mean gradient differs from full-batch gradient: {worst:.3e}"
+
+
+def test_fnet_symmetry_full_size():
+    """y[m,k] == y[(N-m)%N,(D-k)%D] at (512, 65, 512) bf16 -- size-independent property of Re(fft2) of a real tensor,
+    and linearity in fp32."""
+    from spectre_vit import hip_ops
+    torch.manual_seed(0)
+    x = torch.randn(512, 65, 512, device=dev(), dtype=torch.bfloat16)
+    y = hip_ops.FNetMixFn.apply(x)
+    mi = (-torch.arange(65, device=dev())) % 65
+    ki = (-torch.arange(512, device=dev())) % 512
+    assert torch.equal(y, y[:, mi][:, :, ki])
+    a = torch.randn(8, 65, 512, device=dev())
+    b = torch.randn(8, 65, 512, device=dev())
+    lhs = hip_ops.FNetMixFn.apply(a + 2 * b)
+    rhs = hip_ops.FNetMixFn.apply(a) + 2 * hip_ops.FNetMixFn.apply(b)
+    assert (lhs - rhs).abs().max().item() < 1e-3 * lhs.abs().max().item()
+
+
+def test_permut_gather_roundtrip_full_size():
+    """backward(forward(x)) == heads * x  (each head is a signed permutation: P^T P = I)."""
+    from spectre_vit import hip_ops
+    torch.manual_seed(1)
+    H, N, E = 16, 65, 512
+    d = N * E
+    perms = torch.stack([torch.randperm(d) for _ in range(H)]).to(dev())
+    signs = (torch.randint(0, 2, (H, d)).float() * 2 - 1).to(dev())
+    idx = hip_ops.permut_pack(perms, signs)
+    x = torch.randn(32, N, E, device=dev()).requires_grad_(True)
+    g = hip_ops.PermutGatherFn.apply(x, idx, H)
+    g.backward(g.detach())
+    torch.testing.assert_close(x.grad, H * x.detach(), rtol=1e-5, atol=1e-5)
+
+
+def test_state_dict_roundtrip_and_deepcopy():
+    import copy
+    d, cfg = load_model_fixture("model_small_cut")
+    sd = {k[3:]: v for k, v in d.items() if k.startswith("sd.")}
+    m = build(cfg, sd)
+    m2 = copy.deepcopy(m)
+    img = t(d["img"])
+    with torch.no_grad():
+        assert torch.equal(m(img), m2(img))
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape) and str(v.dtype).split(".")[-1] == str(sd[k].dtype), k

@@ -1,0 +1,316 @@
+"""GPU parity tests: every HIP kernel (through the C-ABI, via spectre_vit.hip_ops) against the numpy oracle
+on the same seeded inputs.  Tolerances: fp32 kernels vs float64 oracle  max|err| <= 3e-5 * max|ref| (fp32
+accumulation over K <= 8192); bf16 kernels (bf16 storage, fp32 accumulate) <= 3e-2 * max|ref|."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import spectre_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 3e-5, torch.bfloat16: 3e-2}
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev()).to(dtype)
+
+
+def n64(x):
+    return x.detach().float().cpu().numpy().astype(np.float64)
+
+
+def relerr(got, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(n64(got) - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def check(got, ref, tol, what=""):
+    e = relerr(got, ref)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+
+
+def q(a, dtype):
+    """round inputs to the kernel's storage dtype so the oracle sees the same values"""
+    return n64(t(a, dtype))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from spectre_vit import hip_ops
+    return hip_ops
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,splits", [(300, 200, 64, 1), (128, 128, 128, 1), (1000, 100, 512, 1), (257, 384, 1032, 1),
+                                          (96, 48, 4096, 7), (512, 768, 33280, 12), (5, 12, 8, 1)])
+def test_gemm_nt(ops, dtype, M, N, K, splits):
+    rng = np.random.default_rng(M + N + K)
+    a = q(rng.standard_normal((M, K)), dtype)
+    b = q(rng.standard_normal((N, K)), dtype)
+    bias = rng.standard_normal(N)
+    A, B, bi = t(a, dtype), t(b, dtype), t(bias)
+    C = torch.empty((M, N), dtype=torch.float32, device=dev())
+    ws = torch.empty((splits * M * N,), dtype=torch.float32, device=dev()) if splits > 1 else None
+    ops._gemm(A, B, bi, C, M, N, K, K, K, N, 0, splits, ws)
+    ref = a @ b.T + bias
+    check(C, ref, 2e-5 if dtype == torch.float32 else 1e-4, "gemm")  # inputs already rounded: only accumulation differs
+    # accumulate into an existing C, output in the input dtype
+    C2 = t(rng.standard_normal((M, N)), dtype)
+    c2 = n64(C2)
+    ops._gemm(A, B, None, C2, M, N, K, K, K, N, 1, 1, None)
+    check(C2, a @ b.T + c2, TOL[dtype], "gemm accumulate")
+
+
+def test_gemm_grouped_rows(ops):
+    from spectre_vit import _native
+    rng = np.random.default_rng(3)
+    Bn, Np, K, E = 5, 16, 48, 64
+    a, w = rng.standard_normal((Bn * Np, K)), rng.standard_normal((E, K))
+    pb = rng.standard_normal((Np, E))
+    A, W, PB = t(a), t(w), t(pb)
+    out = torch.zeros((Bn, Np + 1, E), device=dev())
+    _native.call("spv_gemm_nt_grouped_rows", A.data_ptr(), W.data_ptr(), 0, PB.data_ptr(), out.data_ptr(), Bn * Np, E, K, K, K, E,
+                 0, 0, Np, Np + 1, 1, torch.cuda.current_stream().cuda_stream)
+    ref = np.zeros((Bn, Np + 1, E))
+    ref[:, 1:, :] = (a @ w.T).reshape(Bn, Np, E) + pb
+    check(out, ref, 2e-5, "grouped gemm")
+
+
+# ------------------------------------------------------------------------------------------------ SpectreLinear
+def sl_oracle(x, W, b, g, be, dy):
+    p = dict(weight=W, bias=b, ln_weight=g, ln_bias=be)
+    y, c = O.spectre_linear_fwd(x, p)
+    dx, gr = O.spectre_linear_bwd(dy, p, c)
+    return y, dx, gr
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,lead", [(64, 64, (3, 7)), (256, 16, (2, 9)), (96, 64, (5, 3)), (64, 96, (4, 5)),
+                                           (512, 768, (2, 65)), (768, 512, (2, 65)), (512, 104, (33,)), (1024, 64, (130,)),
+                                           (48, 256, (3, 50))])
+def test_spectre_linear(ops, dtype, cin, cout, lead):
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = q(rng.standard_normal(lead + (cin,)), dtype)
+    W = rng.standard_normal((cout, cin)) / np.sqrt(cin)
+    b = rng.standard_normal(cout) * 0.1
+    g = rng.random(cout) + 0.5
+    be = rng.standard_normal(cout) * 0.1
+    dy = q(rng.standard_normal(lead + (cout,)), dtype)
+    Wq = q(W, dtype)  # the kernel multiplies with the dtype shadow of W
+    y_ref, dx_ref, gr = sl_oracle(x, Wq, b, g, be, dy)
+    X = t(x, dtype).requires_grad_(True)
+    Wt, bt, gt, bet = (t(W).requires_grad_(True), t(b).requires_grad_(True), t(g).requires_grad_(True), t(be).requires_grad_(True))
+    Y = ops.spectre_linear(X, Wt, bt, gt, bet, 0.0, False)
+    Y.backward(t(dy, dtype))
+    tol = TOL[dtype]
+    check(Y, y_ref, tol, "y")
+    check(X.grad, dx_ref, tol * 2, "dx")
+    check(Wt.grad, gr["weight"], tol * 2, "dW")
+    check(bt.grad, gr["bias"], tol * 2, "db")
+    check(gt.grad, gr["ln_weight"], tol * 2, "dgamma")
+    check(bet.grad, gr["ln_bias"], tol * 2, "dbeta")
+
+
+def test_spectre_linear_golden(ops, golden_ops):
+    """the reference's own SpectreLinear outputs (tests/golden/ops.npz), fp32 kernels"""
+    g = golden_ops
+    for name in ["sl_equal", "sl_down_exact", "sl_down_overlap", "sl_up"]:
+        X = t(g[f"{name}.x"]).requires_grad_(True)
+        P = [t(g[f"{name}.sd.local_head.{k}"]).requires_grad_(True) for k in ("0.weight", "0.bias", "1.weight", "1.bias")]
+        Y = ops.spectre_linear(X, *P, 0.0, False)
+        Y.backward(t(g[f"{name}.dy"]))
+        check(Y, g[f"{name}.y"], 3e-5, name + ".y")
+        check(X.grad, g[f"{name}.dx"], 6e-5, name + ".dx")
+        for pt, k in zip(P, ("0.weight", "0.bias", "1.weight", "1.bias")):
+            check(pt.grad, g[f"{name}.grad.local_head.{k}"], 6e-5, name + ".grad." + k)
+
+
+def test_spectre_linear_dropout(ops):
+    torch.manual_seed(0)
+    X = torch.randn(4096, 64, device=dev()).requires_grad_(True)
+    W = (torch.randn(64, 64, device=dev()) / 8).requires_grad_(True)
+    z = torch.zeros(64, device=dev(), requires_grad=True)
+    o = torch.ones(64, device=dev(), requires_grad=True)
+    y0 = ops.spectre_linear(X, W, z, o, z, 0.0, False)
+    y1 = ops.spectre_linear(X, W, z, o, z, 0.25, False)
+    kept = (y1 != 0)
+    frac = kept.float().mean().item()
+    assert abs(frac - 0.75) < 0.01, frac
+    torch.testing.assert_close(y1[kept], (y0 / 0.75)[kept], rtol=1e-5, atol=1e-6)
+    y1.sum().backward()  # backward regenerates the same mask: dropped outputs contribute no gradient
+    gx = X.grad.clone()
+    assert torch.isfinite(gx).all()
+
+
+# ------------------------------------------------------------------------------------------------ add + LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("rows,n", [(130, 512), (7, 48), (33, 768), (5, 100), (9, 3072), (6, 1000)])
+def test_add_layernorm(ops, dtype, mode, rows, n):
+    rng = np.random.default_rng(rows + n + mode)
+    a, b = q(rng.standard_normal((rows, n)), dtype), q(rng.standard_normal((rows, n)), dtype)
+    g, be = rng.random(n) + 0.5, rng.standard_normal(n) * 0.1
+    dy = q(rng.standard_normal((rows, n)), dtype)
+    if mode == 0:
+        ln, c = O.layernorm_fwd(a, g, be)
+        ref = ln + b
+    else:
+        ref, c = O.layernorm_fwd(a + b, g, be)
+    din, dg, db = O.layernorm_bwd(dy, g, c)
+    A, Bt = t(a, dtype).requires_grad_(True), t(b, dtype).requires_grad_(True)
+    G, Be = t(g).requires_grad_(True), t(be).requires_grad_(True)
+    Y = ops.add_layernorm(A, Bt, G, Be, mode)
+    Y.backward(t(dy, dtype))
+    tol = TOL[dtype]
+    check(Y, ref, tol, "y")
+    check(A.grad, din, tol * 2, "da")
+    check(Bt.grad, dy if mode == 0 else din, tol * 2, "db")
+    check(G.grad, dg, tol * 2, "dgamma")
+    check(Be.grad, db, tol * 2, "dbeta")
+
+
+# ------------------------------------------------------------------------------------------------ permutation gather
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,E,H", [(3, 5, 8, 3), (2, 65, 64, 4), (2, 65, 512, 16), (2, 100, 512, 2), (2, 7, 12, 5)])
+def test_permut_gather(ops, dtype, B, N, E, H):
+    rng = np.random.default_rng(B + N + E + H)
+    d = N * E
+    perms = np.stack([rng.permutation(d) for _ in range(H)]).astype(np.int64)
+    signs = rng.integers(0, 2, (1, H, d)).astype(np.float64) * 2 - 1
+    x = q(rng.standard_normal((B, N, E)), dtype)
+    dg = q(rng.standard_normal((B, N, E * H)), dtype)
+    idx = ops.permut_pack(torch.from_numpy(perms).to(dev()), t(signs).reshape(H, d))
+    X = t(x, dtype).requires_grad_(True)
+    G = ops.PermutGatherFn.apply(X, idx, H)
+    ref = O.permut_gather_fwd(x, perms, signs)
+    assert np.array_equal(n64(G).reshape(ref.shape), ref), "gather must be bit exact (pure data movement + sign flip)"
+    G.backward(t(dg, dtype).reshape(G.shape))
+    check(X.grad, O.permut_gather_bwd(dg, perms, signs, N, E), 1e-6 if dtype == torch.float32 else 8e-3, "dx")
+
+
+# ------------------------------------------------------------------------------------------------ spectral mixers
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,D", [(3, 65, 512), (2, 5, 16), (2, 50, 48), (2, 17, 64), (4, 65, 128), (2, 6, 8), (2, 4, 1024),
+                                   (2, 79, 256), (1, 197, 96)])
+def test_fnet_mix(ops, dtype, B, N, D):
+    rng = np.random.default_rng(N * 1000 + D)
+    x = q(rng.standard_normal((B, N, D)), dtype)
+    dy = q(rng.standard_normal((B, N, D)), dtype)
+    X = t(x, dtype).requires_grad_(True)
+    Y = ops.FNetMixFn.apply(X)
+    Y.backward(t(dy, dtype))
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    check(Y, O.fnet_mix_fwd(x), tol, "y")
+    check(X.grad, O.fnet_mix_bwd(dy), tol, "dx")
+
+
+def test_fnet_golden(ops, golden_ops):
+    check(ops.FNetMixFn.apply(t(golden_ops["fnet65.x"])), golden_ops["fnet65.y"], 2e-5, "fnet65 vs torch.fft.fft2.real")
+    check(ops.FNetMixFn.apply(t(golden_ops["fnet.x"])), golden_ops["fnet.y"], 2e-5, "fnet vs torch.fft.fft2.real")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rfft_real(ops, golden_ops, dtype):
+    g = golden_ops
+    X = t(q(g["fftmod.x"], dtype), dtype).requires_grad_(True)
+    Y = ops.RfftRealFn.apply(X)
+    Y.backward(t(g["fftmod.dy"], dtype))
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    check(Y, O.fft_module_fwd(q(g["fftmod.x"], dtype)), tol, "y")
+    check(X.grad, O.fft_module_bwd(q(g["fftmod.dy"], dtype), 16), tol, "dx")
+    if dtype == torch.float32:
+        check(Y, g["fftmod.y"], tol, "golden y")
+        check(X.grad, g["fftmod.dx"], tol, "golden dx")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,axis,levels", [((2, 65, 32), 1, 1), ((2, 65, 32), 1, 3), ((3, 5, 64), 2, 1), ((3, 5, 64), 2, 6),
+                                               ((2, 65, 512), 2, 2), ((2, 65, 512), 1, 2)])
+def test_haar_dwt(ops, dtype, shape, axis, levels):
+    rng = np.random.default_rng(levels + axis)
+    x, dy = q(rng.standard_normal(shape), dtype), q(rng.standard_normal(shape), dtype)
+    X = t(x, dtype).requires_grad_(True)
+    Y = ops.HaarDWTFn.apply(X, axis, levels)
+    Y.backward(t(dy, dtype))
+    tol = 1e-6 if dtype == torch.float32 else 1.5e-2
+    check(Y, O.haar_dwt_fwd(x, axis - 3, levels), tol, "y")
+    check(X.grad, O.haar_dwt_bwd(dy, axis - 3, levels), tol, "dx")
+
+
+# ------------------------------------------------------------------------------------------------ patch embeddings
+def test_spectral_patch_embed_golden(ops, golden_ops):
+    from spectre_vit.models.spectre.spectre import SpectralPatchEmbed
+    g = golden_ops
+    m = SpectralPatchEmbed(16, 4, 4, 0.0, 3).to(dev())
+    m.load_state_dict({k[len("spe.sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("spe.sd.")})
+    y = m(t(g["spe.x"]))
+    y.backward(t(g["spe.dy"]))
+    check(y, g["spe.y"], 3e-5, "tokens")
+    for k, p in m.named_parameters():
+        check(p.grad, g["spe.grad." + k], 1e-4, "grad " + k)
+
+
+def test_conv_patch_embed_golden(ops, golden_ops):
+    from spectre_vit.modules.patch_embeddings import PatchEmbedding
+    g = golden_ops
+    m = PatchEmbedding(16, 4, 4, 0.0, 3).to(dev())
+    m.load_state_dict({k[len("pe.sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("pe.sd.")})
+    y = m(t(g["pe.x"]))
+    y.backward(t(g["pe.dy"]))
+    check(y, g["pe.y"], 3e-5, "tokens")
+    for k, p in m.named_parameters():
+        check(p.grad, g["pe.grad." + k], 1e-4, "grad " + k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_spectral_patch_embed_cifar_shape(ops, dtype):
+    from spectre_vit.models.spectre.spectre import SpectralPatchEmbed
+    torch.manual_seed(5)
+    m = SpectralPatchEmbed(512, 4, 64, 0.0, 3).to(dev())
+    with torch.no_grad():
+        m.freq_weight_h.uniform_(0.5, 1.5)
+        m.freq_weight_w.uniform_(0.5, 1.5)
+    x = torch.randn(6, 3, 32, 32, device=dev())
+    dy = torch.randn(6, 65, 512, device=dev())
+    if dtype == torch.bfloat16:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(x)
+    else:
+        y = m(x)
+    assert y.dtype == dtype and y.shape == (6, 65, 512)
+    y.backward(dy.to(dtype))
+    sd = {k: n64(v) for k, v in m.state_dict().items()}
+    p = dict(freq_weight_h=sd["freq_weight_h"], freq_weight_w=sd["freq_weight_w"], proj_weight=sd["proj.weight"],
+             proj_bias=sd["proj.bias"], cls_token=sd["cls_token"], position_embeddings=sd["position_embeddings"])
+    ref, cache = O.spectral_patch_embed_fwd(n64(x), p, 4)
+    gr = O.spectral_patch_embed_bwd(n64(dy.to(dtype)), p, 4, cache)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    check(y, ref, tol, "tokens")
+    check(m.proj.weight.grad, gr["proj_weight"], tol * 3, "dproj")
+    check(m.freq_weight_h.grad, gr["freq_weight_h"], tol * 3, "dfh")
+    check(m.freq_weight_w.grad, gr["freq_weight_w"], tol * 3, "dfw")
+    check(m.position_embeddings.grad, gr["position_embeddings"], tol * 3, "dpos")
+    check(m.cls_token.grad, gr["cls_token"], tol * 3, "dcls")
+    check(m.proj.bias.grad, gr["proj_bias"], tol * 3, "dbias")
+
+
+def test_dropout_kernel(ops):
+    x = torch.ones(1 << 20, device=dev(), requires_grad=True)
+    y = ops.DropoutFn.apply(x, 0.1)
+    frac = (y != 0).float().mean().item()
+    assert abs(frac - 0.9) < 3e-3
+    assert abs(y.mean().item() - 1.0) < 5e-3
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad, y.detach())  # same mask, same scale
+
+
+def test_cpu_tensor_fails_loudly(ops):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.FNetMixFn.apply(torch.randn(2, 5, 16))

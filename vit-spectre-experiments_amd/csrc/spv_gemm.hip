@@ -1,0 +1,264 @@
+// spv_gemm.hip -- C[M,N] = A[M,K] . B[N,K]^T (+bias)(+C), MFMA on gfx950.
+//
+// Both operands are K-contiguous ("NT"), which is the only layout the module mirror ever issues:
+//   forward   h  = x . W^T          A = x [rows,K],   B = W   [N,K]
+//   data grad dx = dh . W           A = dh [rows,N],  B = W^T [K,N]   (W^T kept beside the bf16 shadow of W)
+//   weight grad dW = dh^T . x       A = dh^T [N,rows], B = x^T [K,rows], split-K over rows
+//
+// Tile: 128 x 128 x (128 bytes of K) per 256-thread workgroup; 4 waves as 2 x 2, each wave owns a
+// 64 x 64 block = 2 x 2 MFMA 32x32 accumulators (64 fp32 registers).  LDS rows are 128 B of data + 16 B
+// pad: 16 consecutive rows then cover all 64 banks exactly once for ds_read_b128 (conflict free).
+// Global -> registers -> LDS staging with the next tile's loads issued before the MFMAs of the current
+// one (one barrier pair per K step).  bf16: v_mfma_f32_32x32x16_bf16; fp32: v_mfma_f32_32x32x2_f32
+// (exact fp32 fma chain -- the parity path).
+#include "spv_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 128 + 16;  // LDS bytes per tile row
+constexpr int KBYTES = 128;     // bytes of K per tile row
+
+template <typename T> struct KT { static constexpr int BK = KBYTES / sizeof(T); static constexpr int CH = 16 / sizeof(T); };
+
+template <typename TO> __device__ __forceinline__ void store_out(TO* p, float v);
+template <> __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void store_out<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+template <typename TO> __device__ __forceinline__ float load_out(const TO* p);
+template <> __device__ __forceinline__ float load_out<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load_out<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+// XCD-aware, bijective remap of the linear workgroup id (guide T1): workgroups that share an XCD
+// (id % 8) get a contiguous chunk of tiles, so neighbouring tiles re-use operand panels in that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int id, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, x = id & 7;
+    int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (id >> 3);
+}
+
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                      const float* __restrict__ bias, TO* __restrict__ C,
+                                                      float* __restrict__ ws, int M, int N, int K, int lda,
+                                                      int ldb, int ldc, int k_per_split, int accumulate,
+                                                      int tiles_n, int tiles_mn, int rg, int gs, int roff,
+                                                      const float* __restrict__ bias2d) {
+    constexpr int BK = KT<T>::BK;
+    constexpr int CH = KT<T>::CH;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * ROWB];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + BM * ROWB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int split = blockIdx.y;
+    const int tile = xcd_remap(blockIdx.x, tiles_mn);
+    // consecutive tile ids sweep the N tiles of one M panel -> the A panel is fetched once per XCD
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+
+    // staging map: 128 rows x 8 chunks of 16 B per operand; thread -> (row = tid/8 + 32 i, chunk = tid%8)
+    const int srow = tid >> 3, sch = tid & 7;
+    uint4 ra[4], rb[4];
+    const T* aptr[4];
+    const T* bptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int gm = min(m0 + srow + 32 * i, M - 1);
+        int gn = min(n0 + srow + 32 * i, N - 1);
+        aptr[i] = A + (size_t)gm * lda + sch * CH;
+        bptr[i] = B + (size_t)gn * ldb + sch * CH;
+    }
+    auto load_tile = [&](int k0) {
+        const bool ok = (k0 + sch * CH) < kend;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = ok ? *reinterpret_cast<const uint4*>(aptr[i] + k0) : make_uint4(0, 0, 0, 0);
+            rb[i] = ok ? *reinterpret_cast<const uint4*>(bptr[i] + k0) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4*>(sA + (srow + 32 * i) * ROWB + sch * 16) = ra[i];
+            *reinterpret_cast<uint4*>(sB + (srow + 32 * i) * ROWB + sch * 16) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    const unsigned char* fa0 = sA + (wm * 64 + frow) * ROWB;
+    const unsigned char* fb0 = sB + (wn * 64 + frow) * ROWB;
+
+    load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        store_tile();
+        __syncthreads();
+        if (k0 + BK < kend) load_tile(k0 + BK);
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    a[f] = *reinterpret_cast<const bf16x8*>(fa0 + f * 32 * ROWB + ks * 32 + fh * 16);
+                    b[f] = *reinterpret_cast<const bf16x8*>(fb0 + f * 32 * ROWB + ks * 32 + fh * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // fp32: lane half fh owns k = 16 fh + s (any bijection works as long as A and B agree)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 a[2], b[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    a[f] = *reinterpret_cast<const float4*>(fa0 + f * 32 * ROWB + fh * 64 + q * 16);
+                    b[f] = *reinterpret_cast<const float4*>(fb0 + f * 32 * ROWB + fh * 64 + q * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float bv = (bias != nullptr && ws == nullptr) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row >= M) continue;
+                float v = acc[i][j][r];
+                if (ws != nullptr) {
+                    ws[((size_t)split * M + row) * N + col] = v;
+                } else {
+                    v += bv;
+                    int orow = row;
+                    if (rg > 0) {  // grouped output rows (patch rows -> token rows, skipping each image's CLS row)
+                        orow = (row / rg) * gs + roff + (row % rg);
+                        if (bias2d) v += bias2d[(size_t)(row % rg) * N + col];
+                    }
+                    TO* cp = C + (size_t)orow * ldc + col;
+                    if (accumulate) v += load_out<TO>(cp);
+                    store_out<TO>(cp, v);
+                }
+            }
+        }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                            TO* __restrict__ C, int M, int N, int ldc, int splits,
+                                                            int accumulate) {
+    const size_t total = (size_t)M * N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(e / N), col = (int)(e % N);
+        float v = 0.0f;
+        for (int s = 0; s < splits; ++s) v += ws[(size_t)s * total + e];
+        if (bias) v += bias[col];
+        TO* cp = C + (size_t)row * ldc + col;
+        if (accumulate) v += load_out<TO>(cp);
+        store_out<TO>(cp, v);
+    }
+}
+
+template <typename T, typename TO>
+int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb,
+                int ldc, int accumulate, int splits, void* workspace, hipStream_t st, int rg = 0, int gs = 0, int roff = 0,
+                const float* bias2d = nullptr) {
+    constexpr int BK = KT<T>::BK;
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+    int k_per_split = K;
+    if (splits > 1) {
+        k_per_split = cdiv(cdiv(K, splits), BK) * BK;
+        splits = cdiv(K, k_per_split);
+    }
+    float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
+    dim3 grid(tiles_m * tiles_n, splits);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), grid, dim3(256), 0, st, static_cast<const T*>(A),
+                       static_cast<const T*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
+                       accumulate, tiles_n, tiles_m * tiles_n, rg, gs, roff, bias2d);
+    SPV_LAUNCH_CHECK("spv_gemm_nt");
+    if (splits > 1) {
+        int blocks = (int)std::min<int64_t>(((int64_t)M * N + 255) / 256, 2048);
+        hipLaunchKernelGGL((splitk_reduce_kernel<TO>), dim3(blocks), dim3(256), 0, st, ws, bias, static_cast<TO*>(C), M,
+                           N, ldc, splits, accumulate);
+        SPV_LAUNCH_CHECK("spv_gemm_nt(split-k reduce)");
+    }
+    return 0;
+}
+
+}  // namespace
+
+static int gemm_entry(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      int in_dtype, int out_dtype, int accumulate, int splits, void* workspace, void* stream, int rg, int gs,
+                      int roff, const float* bias2d);
+
+extern "C" int spv_gemm_nt(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb,
+                           int ldc, int in_dtype, int out_dtype, int accumulate, int splits, void* workspace, void* stream) {
+    return gemm_entry(A, B, bias, C, M, N, K, lda, ldb, ldc, in_dtype, out_dtype, accumulate, splits, workspace, stream, 0, 0, 0,
+                      nullptr);
+}
+
+extern "C" int spv_gemm_nt_grouped_rows(const void* A, const void* B, const float* bias, const float* bias2d, void* C, int M,
+                                        int N, int K, int lda, int ldb, int ldc, int in_dtype, int out_dtype,
+                                        int rows_per_group, int group_stride, int row_offset, void* stream) {
+    SPV_CHECK(rows_per_group > 0 && group_stride >= rows_per_group + row_offset && row_offset >= 0,
+              "spv_gemm_nt_grouped_rows: bad grouping %d/%d/%d", rows_per_group, group_stride, row_offset);
+    return gemm_entry(A, B, bias, C, M, N, K, lda, ldb, ldc, in_dtype, out_dtype, 0, 1, nullptr, stream, rows_per_group,
+                      group_stride, row_offset, bias2d);
+}
+
+static int gemm_entry(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                      int in_dtype, int out_dtype, int accumulate, int splits, void* workspace, void* stream, int rg, int gs,
+                      int roff, const float* bias2d) {
+    SPV_CHECK(M > 0 && N > 0 && K > 0, "spv_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
+    SPV_CHECK(in_dtype == SPV_F32 || in_dtype == SPV_BF16, "spv_gemm_nt: bad in_dtype %d", in_dtype);
+    SPV_CHECK(out_dtype == SPV_F32 || out_dtype == SPV_BF16, "spv_gemm_nt: bad out_dtype %d", out_dtype);
+    const int ch = in_dtype == SPV_BF16 ? 8 : 4;
+    SPV_CHECK(K % ch == 0 && lda % ch == 0 && ldb % ch == 0,
+              "spv_gemm_nt: K=%d lda=%d ldb=%d must be multiples of %d elements (16 bytes)", K, lda, ldb, ch);
+    SPV_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "spv_gemm_nt: A/B must be 16-byte aligned");
+    SPV_CHECK(lda >= K && ldb >= K && ldc >= N, "spv_gemm_nt: leading dimension too small");
+    SPV_CHECK(splits >= 1, "spv_gemm_nt: splits=%d", splits);
+    SPV_CHECK(splits == 1 || workspace != nullptr, "spv_gemm_nt: split-K needs a workspace");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (in_dtype == SPV_BF16) {
+        if (out_dtype == SPV_BF16)
+            return launch_gemm<bf16_t, bf16_t>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d);
+        return launch_gemm<bf16_t, float>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d);
+    }
+    if (out_dtype == SPV_BF16)
+        return launch_gemm<float, bf16_t>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d);
+    return launch_gemm<float, float>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d);
+}

@@ -1,0 +1,182 @@
+// spv_misc.hip -- error plumbing + small bandwidth kernels (casts, transposes, GELU, column sums).
+#include "spv_common.h"
+
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+int spv_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+extern "C" int spv_version(void) { return SPV_ABI_VERSION; }
+extern "C" const char* spv_last_error(void) { return g_err; }
+
+namespace {
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[4];
+        io<TI>::ld4(src + 4 * i, v);
+        io<TO>::st4(dst + 4 * i, v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        int64_t i = (n4 << 2) + threadIdx.x;
+        io<TO>::st(dst + i, io<TI>::ld(src + i));
+    }
+}
+
+// dst[c][r] = src[map(r)][c], dst leading dimension ld (>= rows, pad zero filled); 64x64 tile through LDS
+// (+1 pad), 256 threads.  map(r) = r, or with rg > 0 the grouped row (r / rg) * gs + roff + r % rg
+// (token rows of each image minus its CLS row).
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int rows,
+                                                             int cols, int ld, int rg, int gs, int roff) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        int r = r0 + i, c = c0 + tx;
+        float v = 0.0f;
+        if (r < rows && c < cols) {
+            const size_t sr = rg > 0 ? (size_t)(r / rg) * gs + roff + (r % rg) : (size_t)r;
+            v = io<TI>::ld(src + sr * cols + c);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < ld) io<TO>::st(dst + (size_t)c * ld + r, tile[tx][i]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        io<T>::st(y + i, gelu_erf(io<T>::ld(x + i)));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                       T* __restrict__ dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        io<T>::st(dx + i, io<T>::ld(dy + i) * gelu_erf_grad(io<T>::ld(x + i)));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out,
+                                                    float a, float b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        io<T>::st(out + i, a * io<T>::ld(x + i) + b * io<T>::ld(y + i));
+}
+
+// column sums: block b sums rows b, b+G, ... for all columns into partials[b][n]; second kernel folds.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partials, int rows,
+                                                             int n) {
+    for (int c = threadIdx.x; c < n; c += blockDim.x) {
+        float s = 0.0f;
+        for (int r = blockIdx.x; r < rows; r += gridDim.x) s += io<T>::ld(x + (size_t)r * n + c);
+        partials[(size_t)blockIdx.x * n + c] = s;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partials, float* __restrict__ out, int parts,
+                                                          int n) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.0f;
+    for (int p = 0; p < parts; ++p) s += partials[(size_t)p * n + c];
+    out[c] = s;
+}
+
+inline int ew_blocks(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 2048); }
+
+}  // namespace
+
+extern "C" int spv_cast(const void* src, int sd, void* dst, int dd, int64_t n, void* stream) {
+    SPV_CHECK(n >= 0, "spv_cast: n < 0");
+    if (n == 0) return 0;
+    SPV_CHECK(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "spv_cast: pointers must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int g = ew_blocks((n + 3) / 4);
+    if (sd == SPV_F32 && dd == SPV_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(g), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (sd == SPV_BF16 && dd == SPV_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (sd == SPV_F32 && dd == SPV_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+    else if (sd == SPV_BF16 && dd == SPV_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+    else
+        return spv_set_error("spv_cast: bad dtypes %d -> %d", sd, dd);
+    SPV_LAUNCH_CHECK("spv_cast");
+    return 0;
+}
+
+extern "C" int spv_cast_transpose(const void* src, int sd, void* dst, int dd, int rows, int cols, int ld, int rg, int gs,
+                                  int roff, void* stream) {
+    SPV_CHECK(rows > 0 && cols > 0 && ld >= rows, "spv_cast_transpose: bad shape rows=%d cols=%d ld=%d", rows, cols, ld);
+    SPV_CHECK(rg == 0 || (rg > 0 && gs >= rg + roff && roff >= 0), "spv_cast_transpose: bad grouping");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(cols, 64), cdiv(ld, 64));
+    if (sd == SPV_F32 && dd == SPV_BF16)
+        hipLaunchKernelGGL((cast_transpose_kernel<float, bf16_t>), grid, dim3(256), 0, st, (const float*)src, (bf16_t*)dst, rows, cols, ld, rg, gs, roff);
+    else if (sd == SPV_BF16 && dd == SPV_F32)
+        hipLaunchKernelGGL((cast_transpose_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)src, (float*)dst, rows, cols, ld, rg, gs, roff);
+    else if (sd == SPV_F32 && dd == SPV_F32)
+        hipLaunchKernelGGL((cast_transpose_kernel<float, float>), grid, dim3(256), 0, st, (const float*)src, (float*)dst, rows, cols, ld, rg, gs, roff);
+    else if (sd == SPV_BF16 && dd == SPV_BF16)
+        hipLaunchKernelGGL((cast_transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, cols, ld, rg, gs, roff);
+    else
+        return spv_set_error("spv_cast_transpose: bad dtypes %d -> %d", sd, dd);
+    SPV_LAUNCH_CHECK("spv_cast_transpose");
+    return 0;
+}
+
+#define DISPATCH_T(dtype, name, ...)                                        \
+    if (dtype == SPV_F32) { using T = float; __VA_ARGS__; }                 \
+    else if (dtype == SPV_BF16) { using T = bf16_t; __VA_ARGS__; }          \
+    else return spv_set_error("%s: bad dtype %d", name, dtype);
+
+extern "C" int spv_gelu_fwd(const void* x, void* y, int64_t n, int dtype, void* stream) {
+    if (n <= 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, "spv_gelu_fwd",
+               hipLaunchKernelGGL((gelu_fwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, (T*)y, n));
+    SPV_LAUNCH_CHECK("spv_gelu_fwd");
+    return 0;
+}
+extern "C" int spv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, void* stream) {
+    if (n <= 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, "spv_gelu_bwd",
+               hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)dy, (const T*)x, (T*)dx, n));
+    SPV_LAUNCH_CHECK("spv_gelu_bwd");
+    return 0;
+}
+extern "C" int spv_axpby(const void* x, const void* y, void* out, float a, float b, int64_t n, int dtype, void* stream) {
+    if (n <= 0) return 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, "spv_axpby",
+               hipLaunchKernelGGL((axpby_kernel<T>), dim3(ew_blocks(n)), dim3(256), 0, st, (const T*)x, (const T*)y, (T*)out, a, b, n));
+    SPV_LAUNCH_CHECK("spv_axpby");
+    return 0;
+}
+
+// partials: fp32 scratch of >= min(rows,512) * n floats
+extern "C" int spv_colsum(const void* x, float* out, float* partials, int rows, int n, int dtype, void* stream) {
+    SPV_CHECK(rows > 0 && n > 0, "spv_colsum: empty");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int parts = std::min(rows, 512);
+    DISPATCH_T(dtype, "spv_colsum",
+               hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(parts), dim3(256), 0, st, (const T*)x, partials, rows, n));
+    SPV_LAUNCH_CHECK("spv_colsum");
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, partials, out, parts, n);
+    SPV_LAUNCH_CHECK("spv_colsum(fold)");
+    return 0;
+}

@@ -1,0 +1,82 @@
+"""ctypes binding of libspv_hip.so (C-ABI declared in include/spv.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C vit-spectre-experiments_amd/csrc``.
+There is NO fallback: if the shared object is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libspv_hip.so")
+
+c_vp, c_i, c_i64, c_u64, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/spv.h one to one
+SIGNATURES = {
+    "spv_version": [],
+    "spv_last_error": [],
+    "spv_cast": [c_vp, c_i, c_vp, c_i, c_i64, c_vp],
+    "spv_cast_transpose": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "spv_gemm_nt": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
+    "spv_gemm_nt_grouped_rows": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "spv_spectre_tail_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],
+    "spv_spectre_tail_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i,
+                             c_i, c_f, c_u64, c_vp],
+    "spv_rowop_partial_floats": [c_i],
+    "spv_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "spv_add_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "spv_permut_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "spv_permut_gather_fwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "spv_permut_gather_bwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "spv_fnet_mix": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp],
+    "spv_fnet_workspace_floats": [c_i, c_i, c_i],
+    "spv_fnet_twiddle_floats": [c_i],
+    "spv_fnet_make_twiddle": [c_vp, c_i, c_vp],
+    "spv_rfft_real": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "spv_haar_dwt": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
+    "spv_patchify": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "spv_embed_posbias": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "spv_embed_cls_rows": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "spv_spectral_fold": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "spv_spectral_fold_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "spv_dropout": [c_vp, c_vp, c_i64, c_f, c_u64, c_i, c_vp],
+    "spv_gelu_fwd": [c_vp, c_vp, c_i64, c_i, c_vp],
+    "spv_gelu_bwd": [c_vp, c_vp, c_vp, c_i64, c_i, c_vp],
+    "spv_colsum": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "spv_axpby": [c_vp, c_vp, c_vp, c_f, c_f, c_i64, c_i, c_vp],
+}
+_RESTYPES = {"spv_last_error": ctypes.c_char_p, "spv_rowop_partial_floats": c_i64, "spv_fnet_workspace_floats": c_i64,
+             "spv_fnet_twiddle_floats": c_i64}
+_NO_STATUS = set(_RESTYPES) | {"spv_version"}
+
+_lib = None
+
+
+def load():
+    """dlopen libspv_hip.so and attach the signatures.  Raises if the library is absent (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libspv_hip.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C vit-spectre-experiments_amd/csrc` (there is no CPU/PyTorch fallback for the Spectre-ViT kernels)")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, c_i)
+        if lib.spv_version() != 1:
+            raise RuntimeError(f"libspv_hip.so ABI version {lib.spv_version()} != 1")
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; raise RuntimeError(spv_last_error()) on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if name in _NO_STATUS:
+        return rc
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {lib.spv_last_error().decode()}")
+    return 0

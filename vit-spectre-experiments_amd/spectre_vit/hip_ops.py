@@ -1,0 +1,489 @@
+"""torch.autograd Functions over the C-ABI of libspv_hip.so.
+
+Host-side mirror of the arithmetic the reference modules issue as stock ATen ops; every Function
+borrows ``data_ptr()``s, launches on torch's current HIP stream and never synchronises.  Tensors must be
+on a HIP device: a CPU tensor raises (there is deliberately no CPU / eager-PyTorch fallback).
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+
+from . import _native
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"libspv_hip kernels take float32 or bfloat16 tensors, got {t.dtype}") from None
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("Spectre-ViT HIP kernels need tensors on an AMD GPU (cuda/HIP device); "
+                               "there is no CPU fallback in this package")
+
+
+_warned_fp16 = False
+
+
+def compute_dtype(x: torch.Tensor) -> torch.dtype:
+    """dtype the kernels run in for input x: the autocast dtype when autocast is on (bf16; an fp16 autocast
+    region -- spectre_vit/repl/train.py:219 -- is served in bf16, same speed and no loss scaling issues),
+    otherwise x's own dtype (fp32 parity runs, or bf16 activations)."""
+    global _warned_fp16
+    if torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        if dt == torch.float16:
+            if not _warned_fp16:
+                warnings.warn("spectre_vit (MI355X): fp16 autocast is served by the bf16 kernels")
+                _warned_fp16 = True
+            return torch.bfloat16
+        if dt == torch.bfloat16:
+            return torch.bfloat16
+    if x.dtype in (torch.float32, torch.bfloat16):
+        return x.dtype
+    return torch.float32
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """differentiable dtype cast through spv_cast (no-op when already `dtype`)."""
+    if x.dtype == dtype:
+        return x
+    return _Cast.apply(x, dtype)
+
+
+def _raw_cast(x, dtype):
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _native.call("spv_cast", _p(x), _dt(x), _p(out), _DT[dtype], x.numel(), _stream())
+    return out
+
+
+class _Cast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _require_gpu(x)
+        ctx.src = x.dtype
+        return _raw_cast(x, dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _raw_cast(g, ctx.src), None
+
+
+# ------------------------------------------------------------------------------------------------
+# weight shadows: compute-dtype copy of W and of W^T, rebuilt only when the parameter changes
+# ------------------------------------------------------------------------------------------------
+class _ShadowCache:
+    def __init__(self):
+        self._d = {}
+
+    def get(self, w: torch.Tensor, dtype: torch.dtype):
+        key = (id(w), dtype)
+        ent = self._d.get(key)
+        ver = (w.data_ptr(), w._version)
+        if ent is not None and ent[0] == ver:
+            return ent[1], ent[2]
+        n, k = w.shape
+        wd = w.detach()
+        wc = wd if dtype == torch.float32 else torch.empty((n, k), dtype=dtype, device=w.device)
+        if wc is not wd:
+            _native.call("spv_cast", _p(wd), F32, _p(wc), _DT[dtype], wd.numel(), _stream())
+        ldt = (n + 7) // 8 * 8
+        wt = torch.empty((k, ldt), dtype=dtype, device=w.device)
+        _native.call("spv_cast_transpose", _p(wd), F32, _p(wt), _DT[dtype], n, k, ldt, 0, 0, 0, _stream())
+        if len(self._d) > 4096:
+            self._d.clear()
+        self._d[key] = (ver, wc, wt)
+        return wc, wt
+
+
+_shadows = _ShadowCache()
+
+
+def _gemm(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspace=None):
+    _native.call("spv_gemm_nt", _p(a), _p(b), _p(bias), _p(c), M, N, K, lda, ldb, ldc, _dt(a), _dt(c), accumulate, splits,
+                 _p(workspace), _stream())
+
+
+def _weight_grad(dh, x, rows, n, k):
+    """dW[n,k] = dh[rows,n]^T . x[rows,k] as an NT GEMM over row-major transposes, split-K over rows."""
+    dev = dh.device
+    ld = (rows + 7) // 8 * 8
+    dht = torch.empty((n, ld), dtype=dh.dtype, device=dev)
+    xt = torch.empty((k, ld), dtype=x.dtype, device=dev)
+    st = _stream()
+    _native.call("spv_cast_transpose", _p(dh), _dt(dh), _p(dht), _dt(dht), rows, n, ld, 0, 0, 0, st)
+    _native.call("spv_cast_transpose", _p(x), _dt(x), _p(xt), _dt(xt), rows, k, ld, 0, 0, 0, st)
+    dw = torch.empty((n, k), dtype=torch.float32, device=dev)
+    tiles = ((n + 127) // 128) * ((k + 127) // 128)
+    splits = max(1, min(1024 // tiles, (ld + 511) // 512))
+    ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev) if splits > 1 else None
+    _gemm(dht, xt, None, dw, n, k, ld, ld, ld, k, 0, splits, ws)
+    return dw
+
+
+def _new_seed():
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+# ------------------------------------------------------------------------------------------------
+# SpectreLinear: GELU(LN(x W^T + b)) + avgpool(x) [+ dropout]      (reference layers.py:76-101)
+# ------------------------------------------------------------------------------------------------
+class SpectreLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, p_drop, out_fp32):
+        _require_gpu(x, weight)
+        n, k = weight.shape
+        shape = x.shape
+        x2 = x.reshape(-1, k)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        dt = x2.dtype
+        mult = 8 if dt == torch.bfloat16 else 4
+        if n % mult or k % mult:
+            raise ValueError(f"SpectreLinear({k}->{n}) in {dt}: channel counts must be multiples of {mult}")
+        wc, wt = _shadows.get(weight, dt)
+        dev = x2.device
+        h = torch.empty((rows, n), dtype=dt, device=dev)
+        _gemm(x2, wc, bias, h, rows, n, k, k, k, n)
+        out = torch.empty((rows, n), dtype=torch.float32 if out_fp32 else dt, device=dev)
+        mean = torch.empty((rows,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=dev)
+        seed = _new_seed() if p_drop > 0.0 else 0
+        _native.call("spv_spectre_tail_fwd", _p(h), _p(x2), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, n, k,
+                     _dt(h), _dt(out), float(p_drop), seed, _stream())
+        ctx.save_for_backward(x2, h, mean, rstd, weight, gamma, beta)
+        ctx.wt = wt
+        ctx.meta = (shape, rows, n, k, float(p_drop), seed)
+        return out.reshape(*shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, h, mean, rstd, weight, gamma, beta = ctx.saved_tensors
+        shape, rows, n, k, p_drop, seed = ctx.meta
+        dev = x2.device
+        dt = x2.dtype
+        dout2 = dout.reshape(rows, n)
+        if not dout2.is_contiguous():
+            dout2 = dout2.contiguous()
+        dh = torch.empty_like(h)
+        dx = torch.empty_like(x2)
+        dgamma = torch.empty((n,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty_like(dgamma)
+        dbias = torch.empty_like(dgamma)
+        partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=dev)
+        _native.call("spv_spectre_tail_bwd", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
+                     _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed, _stream())
+        wt = ctx.wt  # [k, ld] = W^T
+        ldt = wt.shape[1]
+        if ctx.needs_input_grad[0]:
+            _gemm(dh, wt, None, dx, rows, k, n, n, ldt, k, accumulate=1)
+            dx_out = dx.reshape(shape)
+        else:
+            dx_out = None
+        dw = _weight_grad(dh, x2, rows, n, k)
+        return dx_out, dw, dbias, dgamma, dbeta, None, None
+
+
+def spectre_linear(x, weight, bias, gamma, beta, p_drop=0.0, out_fp32=False):
+    return SpectreLinearFn.apply(x, weight, bias, gamma, beta, p_drop, out_fp32)
+
+
+# ------------------------------------------------------------------------------------------------
+# residual + LayerNorm   mode 0: LN(a) + b (spectre.py:66)    mode 1: LN(a + b) (spectre.py:67)
+# ------------------------------------------------------------------------------------------------
+class AddLayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, mode):
+        _require_gpu(a, b)
+        n = a.shape[-1]
+        a2 = a.reshape(-1, n).contiguous()
+        b2 = b.reshape(-1, n).contiguous()
+        rows = a2.shape[0]
+        out = torch.empty_like(a2)
+        mean = torch.empty((rows,), dtype=torch.float32, device=a.device)
+        rstd = torch.empty_like(mean)
+        _native.call("spv_add_layernorm_fwd", _p(a2), _p(b2), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, n, mode,
+                     _dt(a2), _stream())
+        ctx.save_for_backward(a2, b2, mean, rstd, gamma)
+        ctx.meta = (a.shape, rows, n, mode)
+        return out.reshape(a.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a2, b2, mean, rstd, gamma = ctx.saved_tensors
+        shape, rows, n, mode = ctx.meta
+        d2 = dout.reshape(rows, n).contiguous()
+        din = torch.empty_like(a2)
+        dgamma = torch.empty((n,), dtype=torch.float32, device=a2.device)
+        dbeta = torch.empty_like(dgamma)
+        partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=a2.device)
+        _native.call("spv_add_layernorm_bwd", _p(d2), _p(a2), _p(b2), _p(mean), _p(rstd), _p(gamma), _p(din), _p(dgamma),
+                     _p(dbeta), _p(partials), rows, n, mode, _dt(a2), _stream())
+        din = din.reshape(shape)
+        return din, (dout if mode == 0 else din), dgamma, dbeta, None
+
+
+def add_layernorm(a, b, gamma, beta, mode):
+    return AddLayerNormFn.apply(a, b, gamma, beta, mode)
+
+
+# ------------------------------------------------------------------------------------------------
+# MHPermutMix gather (layers.py:68-72)
+# ------------------------------------------------------------------------------------------------
+def permut_pack(perms: torch.Tensor, signs: torch.Tensor) -> torch.Tensor:
+    _require_gpu(perms, signs)
+    heads, d = perms.shape
+    idx = torch.empty((2, heads, d), dtype=torch.int32, device=perms.device)
+    _native.call("spv_permut_pack", _p(perms.contiguous()), _p(signs.contiguous().float()), _p(idx), heads, d, _stream())
+    return idx
+
+
+class PermutGatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, heads):
+        _require_gpu(x, idx)
+        B = x.shape[0]
+        xc = x.contiguous()
+        d = xc.numel() // B
+        g = torch.empty((B, heads * d), dtype=x.dtype, device=x.device)
+        _native.call("spv_permut_gather_fwd", _p(xc), _p(idx), _p(g), B, heads, d, _dt(xc), _stream())
+        ctx.idx = idx
+        ctx.meta = (x.shape, B, heads, d)
+        return g
+
+    @staticmethod
+    def backward(ctx, dg):
+        shape, B, heads, d = ctx.meta
+        dgc = dg.contiguous()
+        dx = torch.empty((B, d), dtype=dg.dtype, device=dg.device)
+        _native.call("spv_permut_gather_bwd", _p(dgc), _p(ctx.idx), _p(dx), B, heads, d, _dt(dgc), _stream())
+        return dx.reshape(shape), None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# spectral mixers
+# ------------------------------------------------------------------------------------------------
+_twiddles = {}
+
+
+def _fnet_twiddle(tokens, device):
+    key = (tokens, device)
+    t = _twiddles.get(key)
+    if t is None:
+        t = torch.empty((_native.call("spv_fnet_twiddle_floats", tokens),), dtype=torch.float32, device=device)
+        _native.call("spv_fnet_make_twiddle", _p(t), tokens, _stream())
+        _twiddles[key] = t
+    return t
+
+
+def _fnet_raw(x):
+    B, N, D = x.shape
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    wsn = _native.call("spv_fnet_workspace_floats", B, N, D)
+    ws = torch.empty((wsn,), dtype=torch.float32, device=x.device) if wsn else None
+    _native.call("spv_fnet_mix", _p(xc), _p(y), _p(_fnet_twiddle(N, x.device)), B, N, D, _dt(xc), _p(ws), _stream())
+    return y
+
+
+class FNetMixFn(torch.autograd.Function):
+    """y = Re(fft2(x)) over the last two axes; symmetric operator => backward is the same kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        return _fnet_raw(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _fnet_raw(dy)
+
+
+class RfftRealFn(torch.autograd.Function):
+    """rfft(x, dim=-1).real (reference spectre_vit/modules/spectre.py:9-14)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        D = x.shape[-1]
+        xc = x.reshape(-1, D).contiguous()
+        y = torch.empty((xc.shape[0], D // 2 + 1), dtype=x.dtype, device=x.device)
+        _native.call("spv_rfft_real", _p(xc), _p(y), xc.shape[0], D, 0, _dt(xc), _stream())
+        ctx.meta = (x.shape, D)
+        return y.reshape(*x.shape[:-1], D // 2 + 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, D = ctx.meta
+        dyc = dy.reshape(-1, D // 2 + 1).contiguous()
+        dx = torch.empty((dyc.shape[0], D), dtype=dy.dtype, device=dy.device)
+        _native.call("spv_rfft_real", _p(dyc), _p(dx), dyc.shape[0], D, 1, _dt(dyc), _stream())
+        return dx.reshape(shape)
+
+
+def _haar_raw(x, axis, levels, inverse):
+    B, N, D = x.shape
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    scratch = torch.empty_like(xc) if levels > 1 else None
+    _native.call("spv_haar_dwt", _p(xc), _p(y), B, N, D, axis, levels, inverse, _dt(xc), _p(scratch), _stream())
+    return y
+
+
+class HaarDWTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, axis, levels):
+        _require_gpu(x)
+        ctx.meta = (axis, levels)
+        return _haar_raw(x, axis, levels, 0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        axis, levels = ctx.meta
+        return _haar_raw(dy, axis, levels, 1), None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# patch embedding  (spectre.py:124-156, patch_embeddings.py:28-43)
+# ------------------------------------------------------------------------------------------------
+class SpectralFoldFn(torch.autograd.Function):
+    """W_full[e,(c,p,q)] = sum_uv proj_w[e,(c,u,v)] fh[u] fw[v] Re(rfft2_ortho)[(u,v),(p,q)]."""
+
+    @staticmethod
+    def forward(ctx, proj_w, fh, fw, chans, patch):
+        _require_gpu(proj_w)
+        E = proj_w.shape[0]
+        wf = torch.empty((E, chans * patch * patch), dtype=torch.float32, device=proj_w.device)
+        _native.call("spv_spectral_fold", _p(proj_w), _p(fh), _p(fw), _p(wf), E, chans, patch, _stream())
+        ctx.save_for_backward(proj_w, fh, fw)
+        ctx.meta = (E, chans, patch)
+        return wf
+
+    @staticmethod
+    def backward(ctx, dwf):
+        proj_w, fh, fw = ctx.saved_tensors
+        E, chans, patch = ctx.meta
+        dwf = dwf.contiguous()
+        dw = torch.empty_like(proj_w)
+        dfh = torch.empty_like(fh)
+        dfw = torch.empty_like(fw)
+        scratch = torch.empty_like(proj_w)
+        _native.call("spv_spectral_fold_bwd", _p(dwf), _p(proj_w), _p(fh), _p(fw), _p(dw), _p(dfh), _p(dfw), _p(scratch), E,
+                     chans, patch, _stream())
+        return dw, dfh, dfw, None, None
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """tokens[b,0] = cls + pos[0]; tokens[b,1+n] = W_full . patch(b,n) + bias + pos[1+n]."""
+
+    @staticmethod
+    def forward(ctx, img, w_full, bias, cls, pos, patch, dtype):
+        _require_gpu(img, w_full)
+        B, C, H, W = img.shape
+        E, K = w_full.shape
+        Np = (H // patch) * (W // patch)
+        T = Np + 1
+        dev = img.device
+        img = img.contiguous().float()
+        mult = 8 if dtype == torch.bfloat16 else 4
+        if K % mult or E % mult:
+            raise ValueError(f"patch embedding: C*P*P={K} and embed_dim={E} must be multiples of {mult}")
+        st = _stream()
+        patches = torch.empty((B * Np, K), dtype=dtype, device=dev)
+        _native.call("spv_patchify", _p(img), _p(patches), B, C, H, W, patch, K, 0, _DT[dtype], st)
+        wc = w_full if dtype == torch.float32 else _raw_cast(w_full, dtype)
+        posbias = torch.empty((Np, E), dtype=torch.float32, device=dev)
+        _native.call("spv_embed_posbias", _p(pos), _p(bias), _p(posbias), Np, E, st)
+        tokens = torch.empty((B, T, E), dtype=dtype, device=dev)
+        _native.call("spv_gemm_nt_grouped_rows", _p(patches), _p(wc), 0, _p(posbias), _p(tokens), B * Np, E, K, K, K, E,
+                     _DT[dtype], _DT[dtype], Np, T, 1, st)
+        _native.call("spv_embed_cls_rows", _p(cls), _p(pos), _p(tokens), B, T, E, _DT[dtype], st)
+        ctx.save_for_backward(img)
+        ctx.meta = (B, C, H, W, patch, E, K, Np, T, dtype, cls.shape, pos.shape)
+        return tokens
+
+    @staticmethod
+    def backward(ctx, dtok):
+        (img,) = ctx.saved_tensors
+        B, C, H, W, patch, E, K, Np, T, dtype, cls_shape, pos_shape = ctx.meta
+        dev = dtok.device
+        st = _stream()
+        dtok = dtok.contiguous()
+        part = torch.empty((min(B, 512) * T * E,), dtype=torch.float32, device=dev)
+        dpos = torch.empty((T, E), dtype=torch.float32, device=dev)
+        _native.call("spv_colsum", _p(dtok), _p(dpos), _p(part), B, T * E, _dt(dtok), st)
+        dbias = torch.empty((E,), dtype=torch.float32, device=dev)
+        _native.call("spv_colsum", _p(dpos[1:]), _p(dbias), _p(part), T - 1, E, F32, st)
+        dcls = dpos[0].clone().reshape(cls_shape)
+        rows = B * Np
+        ld = (rows + 7) // 8 * 8
+        dyt = torch.empty((E, ld), dtype=dtok.dtype, device=dev)
+        _native.call("spv_cast_transpose", _p(dtok), _dt(dtok), _p(dyt), _dt(dyt), rows, E, ld, Np, T, 1, st)
+        pt = torch.empty((K, ld), dtype=dtok.dtype, device=dev)
+        _native.call("spv_patchify", _p(img), _p(pt), B, C, H, W, patch, ld, 1, _dt(pt), st)
+        dwf = torch.empty((E, K), dtype=torch.float32, device=dev)
+        tiles = ((E + 127) // 128) * ((K + 127) // 128)
+        splits = max(1, min(1024 // tiles, (ld + 511) // 512))
+        ws = torch.empty((splits * E * K,), dtype=torch.float32, device=dev) if splits > 1 else None
+        _gemm(dyt, pt, None, dwf, E, K, ld, ld, ld, K, 0, splits, ws)
+        return None, dwf, dbias, dcls, dpos.reshape(pos_shape), None, None
+
+
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        _require_gpu(x)
+        xc = x.contiguous()
+        seed = _new_seed()
+        y = torch.empty_like(xc)
+        _native.call("spv_dropout", _p(xc), _p(y), xc.numel(), float(p), seed, _dt(xc), _stream())
+        ctx.meta = (float(p), seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.meta
+        dyc = dy.contiguous()
+        dx = torch.empty_like(dyc)
+        _native.call("spv_dropout", _p(dyc), _p(dx), dyc.numel(), p, seed, _dt(dyc), _stream())
+        return dx, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, p)
+
+
+class AddFn(torch.autograd.Function):
+    """out = a + b through spv_axpby (the encoder's global residual, spectre.py:103)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a, b)
+        ac, bc = a.contiguous(), b.contiguous()
+        out = torch.empty_like(ac)
+        _native.call("spv_axpby", _p(ac), _p(bc), _p(out), 1.0, 1.0, ac.numel(), _dt(ac), _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g

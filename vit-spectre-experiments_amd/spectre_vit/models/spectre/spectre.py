@@ -1,0 +1,145 @@
+"""Spectre-ViT -- mirror of reference spectre_vit/models/spectre/spectre.py.
+
+Class names, constructor arguments, forward signatures and state_dict keys follow the reference
+(SURVEY.md 8b); the arithmetic runs in libspv_hip.so.  One labelled extension: ``mixer=`` on
+SpectreViT / SpectreEncoderLayer selects the token mixer ("permut" = the reference's HEAD default
+MHPermutMix, "fft" = FNet Re(fft2), "dwt_embed" / "dwt_token" = Haar DWT) -- the modes the reference's
+docstring lists (spectre.py:30-36) and BASELINE.json benchmarks.
+"""
+import torch
+import torch.nn as nn
+from torch.nn.modules.transformer import _get_activation_fn, _get_clones
+
+from spectre_vit import hip_ops
+from spectre_vit.models.spectre.layers import MHPermutMix, SpectreLinear
+from spectre_vit.modules.mixers import FNetMixer, HaarDWTMixer
+
+MIXERS = ("permut", "fft", "dwt_embed", "dwt_token")
+
+
+class Transpose(nn.Module):
+    """reference spectre.py:8-14 (pure view op)."""
+
+    def __init__(self, dims=(-2, -1)):
+        super(Transpose, self).__init__()
+        self.dims = dims
+
+    def forward(self, x):
+        return x.transpose(self.dims[0], self.dims[1])
+
+
+def _make_mixer(mixer, d_model, seq_length, nhead, dwt_levels):
+    if mixer == "permut":
+        return MHPermutMix(d_model, seq_length, nhead, d_model)
+    if mixer == "fft":
+        return FNetMixer()
+    if mixer == "dwt_embed":
+        return HaarDWTMixer("embed", dwt_levels)
+    if mixer == "dwt_token":
+        return HaarDWTMixer("token", dwt_levels)
+    raise ValueError(f"mixer must be one of {MIXERS}, got {mixer!r}")
+
+
+class SpectreEncoderLayer(nn.Module):
+    """x = norm1(mix(x)) + x ; x = norm2(x + linear3(linear1(x)))   (reference spectre.py:29-73)."""
+
+    def __init__(self, seq_length, d_model, nhead, dim_feedforward, dropout, activation, mixer="permut", dwt_levels=1):
+        super().__init__()
+        bias = True
+        layer_norm_eps = 1e-5
+        self.mixer = mixer
+        self.mix_layer = _make_mixer(mixer, d_model, seq_length, nhead, dwt_levels)
+        self.linear1 = SpectreLinear(d_model, dim_feedforward)
+        self.linear3 = SpectreLinear(dim_feedforward, d_model)
+
+        self.norm1 = nn.LayerNorm(d_model, eps=layer_norm_eps, bias=bias)
+        self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps, bias=bias)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        # dropout1/dropout2 are fused into the SpectreLinear tail kernel (same mask semantics, own RNG stream)
+        self.linear1.drop_p = dropout
+        self.linear3.drop_p = dropout
+
+        if isinstance(activation, str):
+            activation = _get_activation_fn(activation)
+        self.activation = activation  # resolved but never called, as in the reference (spectre.py:60-63)
+
+    def forward(self, x):
+        x = hip_ops.cast(x, hip_ops.compute_dtype(x))
+        x = hip_ops.add_layernorm(self.mix_layer(x), x, self.norm1.weight, self.norm1.bias, 0)
+        x = hip_ops.add_layernorm(self._ff_block(x), x, self.norm2.weight, self.norm2.bias, 1)
+        return x
+
+    def _ff_block(self, x: torch.Tensor) -> torch.Tensor:
+        return self.linear3(self.linear1(x))
+
+
+class SpectreEncoder(nn.Module):
+    """Stack of cloned layers + global residual ``output + src`` (reference spectre.py:76-103)."""
+
+    __constants__ = ["norm"]
+
+    def __init__(self, encoder_layer, num_layers: int, norm=None) -> None:
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward(self, src: torch.Tensor):
+        src = hip_ops.cast(src, hip_ops.compute_dtype(src))
+        output = src
+        for mod in self.layers:
+            output = mod(output)
+        if self.norm is not None:
+            output = self.norm(output)
+        return hip_ops.AddFn.apply(output, src)
+
+
+class SpectralPatchEmbed(nn.Module):
+    """Per-patch Re(rfft2 ortho) * learnable frequency weights -> Linear -> CLS + position (+dropout)
+    (reference spectre.py:106-156).  The fixed DFT map and the frequency weights are folded into the
+    projection matrix (spv_spectral_fold), so the whole embedding is one patch GEMM."""
+
+    def __init__(self, embed_dim, patch_size, num_patches, dropout, in_channels):
+        super().__init__()
+        self.P = patch_size
+        self.embed_dim = embed_dim
+        self.in_channels = in_channels
+        self.freq_weight_h = nn.Parameter(torch.ones(self.P))
+        self.freq_weight_w = nn.Parameter(torch.ones(self.P // 2 + 1))
+        self.proj = nn.Linear(in_channels * self.P * (self.P // 2 + 1), embed_dim)
+        self.cls_token = nn.Parameter(torch.randn(1, 1, embed_dim))
+        self.position_embeddings = nn.Parameter(torch.randn(1, num_patches + 1, embed_dim))
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        dt = hip_ops.compute_dtype(x)
+        C = x.shape[1]
+        w_full = hip_ops.SpectralFoldFn.apply(self.proj.weight, self.freq_weight_h, self.freq_weight_w, C, self.P)
+        tok = hip_ops.PatchEmbedFn.apply(x, w_full, self.proj.bias, self.cls_token, self.position_embeddings, self.P, dt)
+        return hip_ops.dropout(tok, self.dropout.p, self.training)
+
+
+class SpectreViT(nn.Module):
+    """reference spectre.py:159-202."""
+
+    def __init__(self, img_size=32, patch_size=4, in_channels=3, num_classes=10, embed_dim=768, num_encoders=12,
+                 num_heads=12, hidden_dim=3072, dropout=0.1, activation="gelu", mixer="permut", dwt_levels=1):
+        super().__init__()
+        num_patches = (img_size // patch_size) ** 2
+        self.embeddings_block = SpectralPatchEmbed(embed_dim, patch_size, num_patches, dropout, in_channels)
+        encoder_layer = SpectreEncoderLayer(seq_length=num_patches + 1, d_model=embed_dim, nhead=num_heads,
+                                            dim_feedforward=hidden_dim, dropout=dropout, activation=activation,
+                                            mixer=mixer, dwt_levels=dwt_levels)
+        self.encoder_blocks = SpectreEncoder(encoder_layer, num_layers=num_encoders)
+        self.mlp_head = nn.Sequential(SpectreLinear(embed_dim, num_classes))
+        self.mlp_head[0].out_fp32 = True  # logits leave in fp32, as they do under stock autocast (LayerNorm output)
+
+    def forward(self, x, return_features=False):
+        x = self.embeddings_block(x)
+        x = self.encoder_blocks(x)
+        cls_token = x[:, 0, :]
+        x = self.mlp_head(cls_token)
+        if return_features:
+            return x, cls_token
+        return x
