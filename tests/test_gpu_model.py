@@ -53,7 +53,9 @@ def test_model_train_step_golden(name):
         check(p.grad, d["grad." + k], 3e-4, "grad " + k)
     opt.step()
     for k, p in m.named_parameters():
-        check(p, d["after." + k], 1e-5, "after-AdamW " + k)
+        # the first Adam step is lr * g / (|g| + 1e-8): where |g| ~ 1e-7 the fp32 error of g shows up in the update,
+        # so the bound is a fraction of one lr step (1e-3) relative to the weight scale, not machine epsilon
+        check(p, d["after." + k], 2e-4, "after-AdamW " + k)
     with torch.no_grad():
         check(m(img), d["logits_after"], 2e-4, "logits after step")
 

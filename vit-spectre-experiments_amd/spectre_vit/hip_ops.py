@@ -7,6 +7,7 @@ on a HIP device: a CPU tensor raises (there is deliberately no CPU / eager-PyTor
 from __future__ import annotations
 
 import warnings
+import weakref
 
 import torch
 
@@ -90,15 +91,18 @@ class _Cast(torch.autograd.Function):
 # weight shadows: compute-dtype copy of W and of W^T, rebuilt only when the parameter changes
 # ------------------------------------------------------------------------------------------------
 class _ShadowCache:
+    """(weight tensor, dtype) -> (W in dtype, W^T in dtype, padded to 8 columns).  Entries are validated by a weak
+    reference to the parameter (ids and addresses are recycled once a tensor dies) and by its version counter."""
+
     def __init__(self):
         self._d = {}
 
     def get(self, w: torch.Tensor, dtype: torch.dtype):
         key = (id(w), dtype)
         ent = self._d.get(key)
-        ver = (w.data_ptr(), w._version)
-        if ent is not None and ent[0] == ver:
-            return ent[1], ent[2]
+        ver = (w.data_ptr(), w._version, tuple(w.shape))
+        if ent is not None and ent[0]() is w and ent[1] == ver:
+            return ent[2], ent[3]
         n, k = w.shape
         wd = w.detach()
         wc = wd if dtype == torch.float32 else torch.empty((n, k), dtype=dtype, device=w.device)
@@ -107,9 +111,9 @@ class _ShadowCache:
         ldt = (n + 7) // 8 * 8
         wt = torch.empty((k, ldt), dtype=dtype, device=w.device)
         _native.call("spv_cast_transpose", _p(wd), F32, _p(wt), _DT[dtype], n, k, ldt, 0, 0, 0, _stream())
-        if len(self._d) > 4096:
-            self._d.clear()
-        self._d[key] = (ver, wc, wt)
+        if len(self._d) > 1024:
+            self._d = {kk: e for kk, e in self._d.items() if e[0]() is not None}
+        self._d[key] = (weakref.ref(w), ver, wc, wt)
         return wc, wt
 
 
