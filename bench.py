@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the Spectre-ViT-Small training step (CIFAR-100-shaped synthetic input,
+bs 512 per GPU, bf16) on N MI355X -- BASELINE.json's metric.  One JSON line on stdout (rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mixer fft|permut|dwt_embed|dwt_token]
+
+A step = forward + CrossEntropy + backward + (gradient all-reduce) + AdamW on one batch resident in HBM
+(reference loop: spectre_vit/repl/train.py:216-238).  N > 1: launched by torch.distributed.run, one rank per GPU,
+RCCL all-reduce of the gradients overlapped with backward; weak scaling (512 images per GPU).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "vit-spectre-experiments_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# configs/spectre_vit_cifar100.py:3-20 of the reference (Small / CIFAR-100)
+SMALL = dict(img_size=32, patch_size=4, in_channels=3, num_classes=100, embed_dim=512, num_encoders=4, num_heads=16,
+             hidden_dim=768, dropout=0.001, activation="gelu")
+
+
+def cpu_baseline(mixer, seconds_budget=20.0):
+    """The numpy oracle (a port of the reference's CPU path, validated against it by tests/golden) timed on this
+    host: fp32, same model, same step definition, on a bounded sample (bs 32 per step)."""
+    import numpy as np
+    import torch
+    from oracle import spectre_oracle as O
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.manual_seed(42)
+    cfg = dict(SMALL, dropout=0.0)
+    m = SpectreViT(**cfg, mixer=mixer)
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    bs = 32
+    g = torch.Generator().manual_seed(1234)
+    img = torch.randn(bs, 3, 32, 32, generator=g).numpy()
+    labels = torch.randint(0, 100, (bs,), generator=g).numpy()
+    state = {}
+
+    def step():
+        loss, _, _, grads = O.train_step(img, labels, sd, cfg["num_encoders"], cfg["patch_size"], mixer, np.float32)
+        for k, gk in grads.items():
+            mv = state.setdefault(k, [np.zeros_like(gk), np.zeros_like(gk)])
+            sd[k], mv[0], mv[1] = O.adamw_step(sd[k], gk.astype(np.float32), mv[0], mv[1], 1)
+        return loss
+
+    step()  # warm-up (page in BLAS, build DFT tables)
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 50):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return dict(value=round(bs / dt, 2), unit="images/sec", cores=cores, kind="port",
+                sample=f"numpy fp32 oracle, {n} train steps of bs {bs} (same model/mixer, dropout 0), {dt:.2f} s/step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mixer", default="fft", choices=["fft", "permut", "dwt_embed", "dwt_token"])
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from spectre_vit import hip_ops
+    from spectre_vit.dp import GradReducer, broadcast_module
+    from spectre_vit.models.spectre.spectre import SpectreViT
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    torch.manual_seed(42)
+    model = SpectreViT(**SMALL, mixer=args.mixer).to(dev)
+    broadcast_module(model)
+    model.train()
+    torch.manual_seed(1234 + rank)  # per-rank dropout / data streams
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
+    labels = torch.randint(0, 100, (args.batch,), generator=g).to(torch.uint8).to(dev)  # uint8 as train.py:218
+    labels = labels.long()
+    reducer = GradReducer(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, fused=True)
+    crit = torch.nn.CrossEntropyLoss()
+    use_bf16 = args.dtype == "bf16"
+
+    def step():
+        reducer.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+            out = model(img)
+        loss = crit(out, labels)
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        return loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    timer = None
+    if not args.no_roofline and rank == 0:
+        timer = hip_ops.KernelTimer()
+        hip_ops.set_kernel_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    hip_ops.set_kernel_timer(None)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        total_images = args.batch * world * args.steps
+        rec = {
+            "metric": "images/sec training, Spectre-ViT-S CIFAR-100 bs512",
+            "value": round(total_images / elapsed, 1),
+            "unit": "images/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16" if use_bf16 else "f32",
+            "data": "synthetic CIFAR-shaped randn images / randint labels resident in HBM, random-init weights (seed 42)",
+            "config": {"workload": f"Spectre-ViT-Small (E512 H16 F768 L4 P4 N65, 100 classes, dropout 0.001), {args.mixer} mixer, "
+                                   f"train step fwd+CE+bwd+AdamW, bs {args.batch}/GPU",
+                       "mixer": args.mixer, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "final_loss": round(final_loss, 4),
+        }
+        if timer is not None:
+            rec["roofline"] = timer.roofline()
+            rec["kernels"] = timer.summary()
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(args.mixer)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,12 @@ There is NO fallback: if the shared object is missing or a call fails, a Runtime
 import ctypes
 import os
 
+# torch must be imported BEFORE libspv_hip.so is dlopen'ed: the PyTorch-ROCm wheel bundles its own HIP runtime
+# (torch/lib/libamdhip64.so); loading ours first would bind it to /opt/rocm's copy and leave two HIP runtimes in one
+# process (the second one reports "no ROCm-capable device").  With torch first, both share torch's runtime, so
+# torch's streams / allocations are valid handles in our kernels' launches.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libspv_hip.so")
 

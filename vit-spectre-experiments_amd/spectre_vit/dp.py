@@ -1,0 +1,98 @@
+"""Data-parallel gradient exchange for the Spectre-ViT training step.
+
+The reference is single-process (spectre_vit/repl/train.py:41); the step shards naturally over images because no
+op mixes samples, so the only exchange is one gradient all-reduce per step.  One process per GPU,
+``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm); gloo on CPU for the tests.
+
+GradReducer keeps every parameter's ``.grad`` as a view into a few large flat fp32 buckets laid out in reverse
+registration order (~ the order backward produces them: head -> last layer -> ... -> embedding).  A
+post-accumulate hook counts a bucket's parameters; when the bucket is complete its all-reduce is launched
+asynchronously on RCCL's own stream while backward continues, and ``finish()`` waits for all of them before the
+optimizer runs.  xGMI is point-to-point (7 links x ~153 GB/s), so few large buckets are used rather than many
+small ones; ``reduce_dtype=torch.bfloat16`` halves the bytes on the links (sum still accumulated by RCCL in bf16,
+so it is off by default).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 32.0, process_group=None, reduce_dtype=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.reduce_dtype = reduce_dtype
+        self.buckets = []  # dict(flat, params, pending, handle, stage)
+        self._bucket_of = {}
+        if not self.params:
+            return
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        cur, cur_n = [], 0
+        groups = []
+        for p in reversed(self.params):
+            if cur and cur_n + p.numel() > cap:
+                groups.append(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            groups.append(cur)
+        for bi, ps in enumerate(groups):
+            n = sum(p.numel() for p in ps)
+            flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+            off = 0
+            for p in ps:
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self._bucket_of[p] = bi
+            self.buckets.append(dict(flat=flat, params=ps, pending=len(ps), handle=None, stage=None))
+        if self.world > 1:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    # -- per step ---------------------------------------------------------------------------------
+    def zero_grad(self):
+        """replaces optimizer.zero_grad(): gradients live in the flat buckets (keep set_to_none=False semantics)."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["pending"] = len(b["params"])
+            b["handle"] = None
+
+    def _launch(self, b):
+        if self.reduce_dtype is not None and self.reduce_dtype != torch.float32:
+            b["stage"] = b["flat"].to(self.reduce_dtype)
+            b["handle"] = dist.all_reduce(b["stage"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _hook(self, p):
+        b = self.buckets[self._bucket_of[p]]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def finish(self):
+        """wait for every bucket's all-reduce and turn the sum into the mean over ranks."""
+        if self.world == 1:
+            return
+        inv = 1.0 / self.world
+        for b in self.buckets:
+            if b["handle"] is None:  # a parameter of this bucket received no gradient this step
+                self._launch(b)
+            b["handle"].wait()
+            if b["stage"] is not None:
+                b["flat"].copy_(b["stage"])
+                b["stage"] = None
+            b["flat"].mul_(inv)
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0, process_group=None):
+    """make parameters AND buffers (perms/signs are RNG-drawn at construction, reference layers.py:61-64) identical
+    on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=process_group)

@@ -120,7 +120,82 @@ class _ShadowCache:
 _shadows = _ShadowCache()
 
 
+# ------------------------------------------------------------------------------------------------
+# live kernel timing for bench.py's roofline block: HIP events recorded on the launch stream around every call of
+# the selected C-ABI entry points (torch.cuda.Event records on torch's current stream == the stream we launch on)
+# ------------------------------------------------------------------------------------------------
+PEAK_TFLOPS = {BF16: 2500.0, F32: 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+class KernelTimer:
+    def __init__(self):
+        self.records = []  # (name, key, start, end)
+
+    def bracket(self, name, key, launch):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        self.records.append((name, key, e0, e1))
+
+    def _groups(self):
+        torch.cuda.synchronize()
+        groups = {}
+        for name, key, e0, e1 in self.records:
+            g = groups.setdefault((name, key), [0, 0.0])
+            g[0] += 1
+            g[1] += e0.elapsed_time(e1) * 1e-3
+        return groups
+
+    @staticmethod
+    def _work(name, key):
+        if name == "gemm":
+            M, N, K, dt = key
+            return "mfma", 2.0 * M * N * K, PEAK_TFLOPS[dt] * 1e12
+        B, N, D, dt = key  # fnet: read x once + write y once
+        return "hbm", 2.0 * B * N * D * (2 if dt == BF16 else 4), PEAK_HBM_GBS * 1e9
+
+    def summary(self):
+        out = []
+        for (name, key), (cnt, tot) in sorted(self._groups().items(), key=lambda kv: -kv[1][1]):
+            bound, work, peak = self._work(name, key)
+            ach = work * cnt / tot
+            out.append(dict(kernel=name, shape=list(key[:-1]), dtype="bf16" if key[-1] == BF16 else "f32", launches=cnt,
+                            avg_us=round(tot / cnt * 1e6, 2), total_ms=round(tot * 1e3, 3), bound=bound,
+                            achieved=round(ach / (1e12 if bound == "mfma" else 1e9), 2),
+                            unit="TFLOP/s" if bound == "mfma" else "GB/s", frac=round(ach / peak, 4)))
+        return out
+
+    def roofline(self):
+        """the single (kernel, shape) with the largest total time in the timed region"""
+        s = self.summary()
+        if not s:
+            return None
+        d = s[0]
+        peak = (PEAK_TFLOPS[BF16 if d["dtype"] == "bf16" else F32]) if d["bound"] == "mfma" else PEAK_HBM_GBS
+        return dict(bound=d["bound"], achieved=d["achieved"], peak=peak, unit=d["unit"], frac=d["frac"], traffic=None,
+                    kernel=d["kernel"], shape=d["shape"], avg_us=d["avg_us"], launches=d["launches"])
+
+
+_timer = None
+
+
+def set_kernel_timer(t):
+    global _timer
+    _timer = t
+
+
 def _gemm(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspace=None):
+    if _timer is not None:
+        _timer.bracket("gemm", (M, N, K, _dt(a)), lambda: _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate, splits,
+                                                                        workspace))
+    else:
+        _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate, splits, workspace)
+
+
+def _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspace=None):
     _native.call("spv_gemm_nt", _p(a), _p(b), _p(bias), _p(c), M, N, K, lda, ldb, ldc, _dt(a), _dt(c), accumulate, splits,
                  _p(workspace), _stream())
 
@@ -304,7 +379,15 @@ def _fnet_raw(x):
     y = torch.empty_like(xc)
     wsn = _native.call("spv_fnet_workspace_floats", B, N, D)
     ws = torch.empty((wsn,), dtype=torch.float32, device=x.device) if wsn else None
-    _native.call("spv_fnet_mix", _p(xc), _p(y), _p(_fnet_twiddle(N, x.device)), B, N, D, _dt(xc), _p(ws), _stream())
+    tw = _fnet_twiddle(N, x.device)
+
+    def launch():
+        _native.call("spv_fnet_mix", _p(xc), _p(y), _p(tw), B, N, D, _dt(xc), _p(ws), _stream())
+
+    if _timer is not None:
+        _timer.bracket("fnet_mix", (B, N, D, _dt(xc)), launch)
+    else:
+        launch()
     return y
 
 
