@@ -1,0 +1,98 @@
+"""CPU-side checks (no GPU compute): the C-ABI library loads and exports every symbol include/spv.h declares, the
+module mirror keeps the reference's state_dict ABI, the host-side FFT harness passes, CPU tensors fail loudly."""
+import copy
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_model_fixture
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    return True
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "spv.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(spv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    from spectre_vit import _native
+    lib = _native.load()
+    names = header_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/spv.h but not exported by libspv_hip.so"
+        assert n in _native.SIGNATURES, f"{n} has no ctypes signature in spectre_vit/_native.py"
+    assert set(_native.SIGNATURES) == set(names), set(_native.SIGNATURES) ^ set(names)
+    assert lib.spv_version() == 1
+
+
+def test_fft_core_host_harness(built):
+    exe = os.path.join(ROOT, "tests", "cpu_harness", "_build", "fft_core_test")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("name", ["model_tiny_mnist", "model_small_cut"])
+def test_state_dict_abi_matches_reference(name):
+    """keys, shapes and dtypes of the reference's own state_dict (tests/golden) == ours; strict load works on CPU."""
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    d, cfg = load_model_fixture(name)
+    ref = {k[3:]: v for k, v in d.items() if k.startswith("sd.")}
+    m = SpectreViT(**cfg)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())  # same names in the same registration order
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref[k].shape), k
+        assert str(v.dtype).replace("torch.", "") == str(ref[k].dtype), k
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == sum(v.size for k, v in ref.items() if "grad." + k in d)
+
+
+def test_clones_share_initial_weights_and_deepcopy():
+    """_get_clones deep-copies one layer: all layers start identical incl. perms/signs."""
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    torch.manual_seed(0)
+    m = SpectreViT(img_size=16, patch_size=4, in_channels=3, num_classes=10, embed_dim=32, num_encoders=3, num_heads=2,
+                   hidden_dim=48, dropout=0.1)
+    l0, l2 = m.encoder_blocks.layers[0], m.encoder_blocks.layers[2]
+    assert torch.equal(l0.mix_layer.perms, l2.mix_layer.perms) and torch.equal(l0.mix_layer.signs, l2.mix_layer.signs)
+    assert torch.equal(l0.linear1.local_head[0].weight, l2.linear1.local_head[0].weight)
+    m2 = copy.deepcopy(m)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_mixer_variants_have_no_permut_buffers():
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    for mixer in ("fft", "dwt_embed", "dwt_token"):
+        m = SpectreViT(img_size=16, patch_size=4, in_channels=3, num_classes=10, embed_dim=32, num_encoders=2, num_heads=2,
+                       hidden_dim=48, dropout=0.0, mixer=mixer)
+        assert not any("perms" in k for k in m.state_dict())
+    with pytest.raises(ValueError):
+        SpectreViT(img_size=16, patch_size=4, embed_dim=32, num_encoders=1, num_heads=2, hidden_dim=48, mixer="nope")
+
+
+def test_cpu_tensors_fail_loudly(built):
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    m = SpectreViT(img_size=16, patch_size=4, in_channels=3, num_classes=10, embed_dim=32, num_encoders=1, num_heads=2,
+                   hidden_dim=48, dropout=0.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(2, 3, 16, 16))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "vit-spectre-experiments_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                assert "oracle" not in open(os.path.join(dp, f)).read().replace("oracle/", "").lower() or f == "__init__.py", f

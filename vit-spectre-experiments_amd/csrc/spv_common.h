@@ -80,6 +80,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * __expf(-0.5f * x * x) * 0.39894228040143267794f;
 }
 
+// bf16 path: GELU and its derivative from one exp and one rcp (Abramowitz-Stegun 7.1.26 erfc, |err| <= 1.5e-7, far
+// below bf16 resolution); the fp32 parity path keeps erff.
+__device__ __forceinline__ void gelu_fast(float x, float& g, float& dg) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float u = __expf(-z * z);  // = exp(-x^2 / 2)
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float half_erfc = 0.5f * poly * u;
+    const float phi = x >= 0.0f ? 1.0f - half_erfc : half_erfc;
+    g = x * phi;
+    dg = fmaf(x * u, 0.39894228040143267794f, phi);
+}
+
 // Counter-based dropout mask: keep(seed, element index) -- regenerated identically in the backward,
 // so no mask tensor is stored.  (The stream differs from torch's Philox; parity runs use p = 0.)
 __device__ __forceinline__ unsigned mix32(unsigned x) {

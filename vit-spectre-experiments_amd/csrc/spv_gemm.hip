@@ -146,34 +146,97 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
         __syncthreads();
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // epilogue: the accumulators go through a wave-private fp32 LDS stage ([32 rows][64 + 4 pad]) so that every
+    // lane leaves with 8 CONSECUTIVE columns of one row: 16-byte (bf16) / 2 x 16-byte (fp32) global stores, 8 rows x
+    // 128 B per wave instruction, instead of 64 two-byte stores per lane (store-issue bound).
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+    float* stage = reinterpret_cast<float*>(smem + wave * (BM * ROWB / 2));  // 9216 B per wave >= 32 * 68 * 4
+    constexpr int SLD = 68;
+    const bool vec_c = ((size_t)ldc * sizeof(TO)) % 16 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    const bool vec_ws = (N & 3) == 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (col >= N) continue;
-            const float bv = (bias != nullptr && ws == nullptr) ? bias[col] : 0.0f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row >= M) continue;
-                float v = acc[i][j][r];
-                if (ws != nullptr) {
-                    ws[((size_t)split * M + row) * N + col] = v;
+            for (int r = 0; r < 16; ++r)
+                stage[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + j * 32 + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int qd = lane + 64 * t;
+            const int lr = qd >> 3, c8 = qd & 7;
+            const int row = m0 + wm * 64 + i * 32 + lr;
+            const int col0 = n0 + wn * 64 + c8 * 8;
+            if (row >= M || col0 >= N) continue;
+            float v[8];
+            {
+                const float4 lo = *reinterpret_cast<const float4*>(stage + lr * SLD + c8 * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(stage + lr * SLD + c8 * 8 + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            }
+            const int nvalid = min(8, N - col0);
+            if (ws != nullptr) {
+                float* wp = ws + ((size_t)split * M + row) * N + col0;
+                if (nvalid == 8 && vec_ws) {
+                    *reinterpret_cast<float4*>(wp) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(wp + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 } else {
-                    v += bv;
-                    int orow = row;
-                    if (rg > 0) {  // grouped output rows (patch rows -> token rows, skipping each image's CLS row)
-                        orow = (row / rg) * gs + roff + (row % rg);
-                        if (bias2d) v += bias2d[(size_t)(row % rg) * N + col];
+                    for (int u = 0; u < nvalid; ++u) wp[u] = v[u];
+                }
+                continue;
+            }
+            int orow = row;
+            const float* b2 = nullptr;
+            if (rg > 0) {  // grouped output rows (patch rows -> token rows, skipping each image's CLS row)
+                orow = (row / rg) * gs + roff + (row % rg);
+                if (bias2d) b2 = bias2d + (size_t)(row % rg) * N + col0;
+            }
+            TO* cp = C + (size_t)orow * ldc + col0;
+            if (nvalid == 8 && vec_c) {
+                if (bias != nullptr) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bias + col0), b1 = *reinterpret_cast<const float4*>(bias + col0 + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (b2 != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] += b2[u];
+                }
+                if constexpr (sizeof(TO) == 2) {
+                    if (accumulate) {
+                        const uint4 old = *reinterpret_cast<const uint4*>(cp);
+                        v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                        v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                        v[4] += __uint_as_float(old.z << 16); v[5] += __uint_as_float(old.z & 0xffff0000u);
+                        v[6] += __uint_as_float(old.w << 16); v[7] += __uint_as_float(old.w & 0xffff0000u);
                     }
-                    TO* cp = C + (size_t)orow * ldc + col;
-                    if (accumulate) v += load_out<TO>(cp);
-                    store_out<TO>(cp, v);
+                    uint4 o;
+                    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+                    o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(cp) = o;
+                } else {
+                    float4* c4 = reinterpret_cast<float4*>(cp);
+                    if (accumulate) {
+                        const float4 o0 = c4[0], o1 = c4[1];
+                        v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+                    }
+                    c4[0] = make_float4(v[0], v[1], v[2], v[3]);
+                    c4[1] = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            } else {
+                for (int u = 0; u < nvalid; ++u) {
+                    float x = v[u];
+                    if (bias != nullptr) x += bias[col0 + u];
+                    if (b2 != nullptr) x += b2[u];
+                    if (accumulate) x += load_out<TO>(cp + u);
+                    store_out<TO>(cp + u, x);
                 }
             }
         }
+    }
 }
 
 template <typename TO>

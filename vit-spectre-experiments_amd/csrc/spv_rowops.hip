@@ -4,14 +4,20 @@
 // Mapping: one wave64 per row, the whole row cached in registers (VEC contiguous elements per lane per
 // step, 16 B / 8 B vector accesses for VEC = 4), wave shuffles for the two LayerNorm reductions, fp32
 // statistics.  Column reductions of the backward (dgamma, dbeta, dbias) are carried in registers across
-// the rows a wave owns, folded across the 4 waves of a workgroup through LDS in a fixed order, written
+// the rows a wave owns, folded across the 8 waves of a workgroup through LDS in a fixed order, written
 // as one slab per workgroup and folded by a second tiny kernel: deterministic, no atomics.
 #include "spv_common.h"
 
 namespace {
 
 constexpr float LN_EPS = 1e-5f;
-constexpr int BWD_MAX_WG = 256;
+constexpr int RT = 256;           // threads per workgroup (4 waves; 3-4 workgroups per CU keep 12-16 rows in flight)
+constexpr int RW = RT / 64;       // waves (= rows in flight) per workgroup
+constexpr int BWD_MAX_WG = 1024;  // backward grids are capped here: one partial slab per workgroup
+
+// how the avg-pool skip maps channels: identity, exact windows of k_in/n inputs, or the general
+// overlapping/up-sampling windows (tables built once per workgroup in LDS, no per-element division)
+enum PoolMode { POOL_IDENT = 0, POOL_EXACT = 1, POOL_TABLE = 2 };
 
 template <int VEC> __device__ __forceinline__ void ldv(const void* base, size_t off, int bf, float (&v)[VEC]);
 template <> __device__ __forceinline__ void ldv<4>(const void* base, size_t off, int bf, float (&v)[4]) {
@@ -39,9 +45,10 @@ __device__ __forceinline__ void st1(void* base, size_t off, int bf, float v) {
 }
 
 // window of nn.AdaptiveAvgPool1d(n_out) output i over n_in inputs: [floor(i in/out), ceil((i+1) in/out))
+// (32-bit arithmetic: the host checks n_in * n_out < 2^31)
 __device__ __forceinline__ void pool_window(int i, int n_in, int n_out, int& s, int& e) {
-    s = (int)(((long long)i * n_in) / n_out);
-    e = (int)((((long long)(i + 1)) * n_in + n_out - 1) / n_out);
+    s = (int)(((unsigned)i * (unsigned)n_in) / (unsigned)n_out);
+    e = (int)((((unsigned)(i + 1)) * (unsigned)n_in + (unsigned)n_out - 1u) / (unsigned)n_out);
 }
 
 // mean / rstd of a register-cached row (two-pass, fp32)
@@ -65,10 +72,10 @@ __device__ __forceinline__ void row_stats(const float (&v)[MAXI][VEC], int n, in
     rstd = rsqrtf(wave_sum(q) / (float)n + LN_EPS);
 }
 
-// fold per-wave column partials (NP arrays) of the 4 waves through LDS in wave order, write the slab.
+// fold per-wave column partials (NP arrays) of the workgroup's waves through LDS in wave order, write the slab.
 template <int VEC, int MAXI, int NP>
 __device__ __forceinline__ void write_partials(float (&acc)[NP][MAXI][VEC], float* lds, float* slab, int n, int lane, int wave) {
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < RW; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int p = 0; p < NP; ++p)
@@ -91,14 +98,29 @@ __device__ __forceinline__ void write_partials(float (&acc)[NP][MAXI][VEC], floa
 
 // ------------------------------------------------------------------------------------------------
 template <int VEC, int MAXI>
-__global__ __launch_bounds__(256) void tail_fwd_kernel(const void* __restrict__ h, const void* __restrict__ x,
+__global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h, const void* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        void* __restrict__ out, float* __restrict__ mean_o,
                                                        float* __restrict__ rstd_o, int rows, int n, int k_in, int bf,
-                                                       int out_bf, float p_drop, uint64_t seed) {
+                                                       int out_bf, float p_drop, uint64_t seed, int pool_mode) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int* win_s = reinterpret_cast<int*>(lds);  // POOL_TABLE: window start / end per output channel
+    int* win_e = win_s + n;
+    if (pool_mode == POOL_TABLE) {
+        for (int c = threadIdx.x; c < n; c += RT) {
+            int s, e;
+            pool_window(c, k_in, n, s, e);
+            win_s[c] = s;
+            win_e[c] = e;
+        }
+        __syncthreads();
+    }
+    const int pw = k_in / n;  // POOL_EXACT window
+    const float inv_pw = 1.0f / (float)(pw > 0 ? pw : 1);
     const int lane = threadIdx.x & 63;
-    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
+    float* xs = lds + 2 * n + (threadIdx.x >> 6) * k_in;  // POOL_TABLE: this wave's fp32 copy of the input row
+    const int wave_g = blockIdx.x * RW + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * RW;
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
     for (int row = wave_g; row < rows; row += nwaves) {
         float hv[MAXI][VEC];
@@ -113,6 +135,19 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const void* __restrict__ 
         }
         float mean, rstd;
         row_stats<VEC, MAXI>(hv, n, lane, mean, rstd);
+        if (pool_mode == POOL_TABLE) {
+            __threadfence_block();  // previous row's pooled reads are done before the stage is overwritten
+            if ((k_in & 3) == 0) {
+                for (int j = lane * 4; j < k_in; j += 256) {
+                    float t4[4];
+                    ldv<4>(x, (size_t)row * k_in + j, bf, t4);
+                    *reinterpret_cast<float4*>(xs + j) = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                }
+            } else {
+                for (int j = lane; j < k_in; j += 64) xs[j] = ld1(x, (size_t)row * k_in + j, bf);
+            }
+            __threadfence_block();  // same-wave LDS traffic is in order; the fence keeps the compiler from reordering
+        }
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int e0 = (i * 64 + lane) * VEC;
@@ -120,22 +155,42 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const void* __restrict__ 
             float g[VEC], b[VEC], pv[VEC], o[VEC];
             ldv<VEC>(gamma, e0, 0, g);
             ldv<VEC>(beta, e0, 0, b);
-            if (k_in == n) {
+            if (pool_mode == POOL_IDENT) {
                 ldv<VEC>(x, (size_t)row * k_in + e0, bf, pv);
+            } else if (pool_mode == POOL_EXACT) {
+                // this lane's VEC outputs average VEC*pw contiguous inputs
+                const size_t xb = (size_t)row * k_in + (size_t)e0 * pw;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    float acc = 0.0f;
+                    if (VEC == 4 && (pw & 3) == 0) {
+                        for (int j = 0; j < pw; j += 4) {
+                            float t4[VEC];
+                            ldv<VEC>(x, xb + (size_t)k * pw + j, bf, t4);
+#pragma unroll
+                            for (int u = 0; u < VEC; ++u) acc += t4[u];
+                        }
+                    } else {
+                        for (int j = 0; j < pw; ++j) acc += ld1(x, xb + (size_t)k * pw + j, bf);
+                    }
+                    pv[k] = acc * inv_pw;
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    int s, e;
-                    pool_window(e0 + k, k_in, n, s, e);
+                    const int s = win_s[e0 + k], e = win_e[e0 + k];
                     float acc = 0.0f;
-                    for (int j = s; j < e; ++j) acc += ld1(x, (size_t)row * k_in + j, bf);
+                    for (int j = s; j < e; ++j) acc += xs[j];
                     pv[k] = acc / (float)(e - s);
                 }
             }
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 float ln = (hv[i][k] - mean) * rstd * g[k] + b[k];
-                o[k] = gelu_erf(ln) + pv[k];
+                float act, dact_unused;
+                if (bf) gelu_fast(ln, act, dact_unused);
+                else act = gelu_erf(ln);
+                o[k] = act + pv[k];
                 if (p_drop > 0.0f) o[k] *= dropout_scale(seed, (uint64_t)row * n + e0 + k, p_drop, inv_keep);
             }
             stv<VEC>(out, (size_t)row * n + e0, out_bf, o);
@@ -145,17 +200,36 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const void* __restrict__ 
 }
 
 template <int VEC, int MAXI>
-__global__ __launch_bounds__(256) void tail_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ h,
+__global__ __launch_bounds__(RT) void tail_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ h,
                                                        const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        void* __restrict__ dh, void* __restrict__ dxp,
                                                        float* __restrict__ partials, int rows, int n, int k_in, int bf,
-                                                       int dout_bf, float p_drop, uint64_t seed) {
+                                                       int dout_bf, float p_drop, uint64_t seed, int pool_mode) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // LDS: [3n] partial fold | POOL_TABLE: c_lo[k_in], c_hi[k_in], inv_w[n]
+    int* c_lo_t = reinterpret_cast<int*>(lds + 3 * n);
+    int* c_hi_t = c_lo_t + k_in;
+    float* inv_w_t = reinterpret_cast<float*>(c_hi_t + k_in);
+    if (pool_mode == POOL_TABLE) {
+        for (int j = threadIdx.x; j < k_in; j += RT) {
+            c_lo_t[j] = (int)(((unsigned)j * (unsigned)n) / (unsigned)k_in);
+            c_hi_t[j] = (int)((((unsigned)(j + 1)) * (unsigned)n + (unsigned)k_in - 1u) / (unsigned)k_in) - 1;
+        }
+        for (int c = threadIdx.x; c < n; c += RT) {
+            int s, e;
+            pool_window(c, k_in, n, s, e);
+            inv_w_t[c] = 1.0f / (float)(e - s);
+        }
+        __syncthreads();
+    }
+    const int pw = k_in / n;
+    const float inv_pw = 1.0f / (float)(pw > 0 ? pw : 1);
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wave_g = blockIdx.x * 4 + wave;
-    const int nwaves = gridDim.x * 4;
+    float* ds = inv_w_t + n + wave * n;  // POOL_TABLE: this wave's fp32 copy of the masked dout row
+    const int wave_g = blockIdx.x * RW + wave;
+    const int nwaves = gridDim.x * RW;
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
     float acc[3][MAXI][VEC];  // 0: dgamma, 1: dbeta, 2: dbias
 #pragma unroll
@@ -184,7 +258,10 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const void* __restrict__ 
                     if (p_drop > 0.0f) d *= dropout_scale(seed, (uint64_t)row * n + e0 + k, p_drop, inv_keep);
                     dv[k] = d;
                     float xhat = (hv[k] - mean) * rstd;
-                    float dln = d * gelu_erf_grad(xhat * g[k] + b[k]);
+                    float dgel, act_unused;
+                    if (bf) gelu_fast(xhat * g[k] + b[k], act_unused, dgel);
+                    else dgel = gelu_erf_grad(xhat * g[k] + b[k]);
+                    float dln = d * dgel;
                     acc[0][i][k] += dln * xhat;
                     acc[1][i][k] += dln;
                     float t = dln * g[k];
@@ -193,13 +270,18 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const void* __restrict__ 
                     s1 += t;
                     s2 += t * xhat;
                 }
-                if (k_in == n) stv<VEC>(dxp, (size_t)row * k_in + e0, bf, dv);  // identity skip
+                if (pool_mode == POOL_IDENT) stv<VEC>(dxp, (size_t)row * k_in + e0, bf, dv);  // identity skip
+                else if (pool_mode == POOL_TABLE) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) ds[e0 + k] = dv[k];
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) { xh[i][k] = 0.0f; dxh[i][k] = 0.0f; }
             }
         }
         const float m1 = wave_sum(s1) / (float)n, m2 = wave_sum(s2) / (float)n;
+        if (pool_mode == POOL_TABLE) __threadfence_block();
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int e0 = (i * 64 + lane) * VEC;
@@ -212,34 +294,49 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const void* __restrict__ 
             }
             stv<VEC>(dh, (size_t)row * n + e0, bf, o);
         }
-        if (k_in != n) {
-            // transposed pooling: input j receives dout[c] / width(c) from every window c that covers j
-            for (int j = lane; j < k_in; j += 64) {
-                const int c_lo = (int)(((long long)j * n) / k_in);
-                const int c_hi = (int)((((long long)(j + 1)) * n + k_in - 1) / k_in) - 1;
-                float a = 0.0f;
-                for (int c = c_lo; c <= c_hi; ++c) {
-                    int s, e;
-                    pool_window(c, k_in, n, s, e);
+        if (pool_mode == POOL_EXACT) {
+            // transposed pooling, exact windows: input j receives dout[j / pw] / pw
+            if (VEC == 4 && (pw & 3) == 0) {
+                for (int j0 = lane * 4; j0 < k_in; j0 += 256) {
+                    const int c = j0 / pw;
                     float d = ld1(dout, (size_t)row * n + c, dout_bf);
                     if (p_drop > 0.0f) d *= dropout_scale(seed, (uint64_t)row * n + c, p_drop, inv_keep);
-                    a += d / (float)(e - s);
+                    d *= inv_pw;
+                    float o[VEC];
+#pragma unroll
+                    for (int u = 0; u < VEC; ++u) o[u] = d;
+                    stv<VEC>(dxp, (size_t)row * k_in + j0, bf, o);
                 }
+            } else {
+                for (int j = lane; j < k_in; j += 64) {
+                    const int c = j / pw;
+                    float d = ld1(dout, (size_t)row * n + c, dout_bf);
+                    if (p_drop > 0.0f) d *= dropout_scale(seed, (uint64_t)row * n + c, p_drop, inv_keep);
+                    st1(dxp, (size_t)row * k_in + j, bf, d * inv_pw);
+                }
+            }
+        } else if (pool_mode == POOL_TABLE) {
+            // transposed pooling: input j receives dout[c] / width(c) from every window c that covers j
+            for (int j = lane; j < k_in; j += 64) {
+                const int c_lo = c_lo_t[j], c_hi = c_hi_t[j];
+                float a = 0.0f;
+                for (int c = c_lo; c <= c_hi; ++c) a += ds[c] * inv_w_t[c];
                 st1(dxp, (size_t)row * k_in + j, bf, a);
             }
+            __threadfence_block();  // pooled reads done before the next row overwrites the stage
         }
     }
     write_partials<VEC, MAXI, 3>(acc, lds, partials + (size_t)blockIdx.x * 3 * n, n, lane, wave);
 }
 
 template <int VEC, int MAXI>
-__global__ __launch_bounds__(256) void addln_fwd_kernel(const void* __restrict__ a, const void* __restrict__ b,
+__global__ __launch_bounds__(RT) void addln_fwd_kernel(const void* __restrict__ a, const void* __restrict__ b,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         void* __restrict__ out, float* __restrict__ mean_o,
                                                         float* __restrict__ rstd_o, int rows, int n, int mode, int bf) {
     const int lane = threadIdx.x & 63;
-    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
+    const int wave_g = blockIdx.x * RW + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * RW;
     for (int row = wave_g; row < rows; row += nwaves) {
         float v[MAXI][VEC], res[MAXI][VEC];
 #pragma unroll
@@ -278,7 +375,7 @@ __global__ __launch_bounds__(256) void addln_fwd_kernel(const void* __restrict__
 }
 
 template <int VEC, int MAXI>
-__global__ __launch_bounds__(256) void addln_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ a,
+__global__ __launch_bounds__(RT) void addln_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ a,
                                                         const void* __restrict__ b, const float* __restrict__ mean_i,
                                                         const float* __restrict__ rstd_i, const float* __restrict__ gamma,
                                                         void* __restrict__ din, float* __restrict__ partials, int rows, int n,
@@ -286,8 +383,8 @@ __global__ __launch_bounds__(256) void addln_bwd_kernel(const void* __restrict__
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int wave_g = blockIdx.x * 4 + wave;
-    const int nwaves = gridDim.x * 4;
+    const int wave_g = blockIdx.x * RW + wave;
+    const int nwaves = gridDim.x * RW;
     float acc[2][MAXI][VEC];
 #pragma unroll
     for (int p = 0; p < 2; ++p)
@@ -343,17 +440,37 @@ __global__ __launch_bounds__(256) void addln_bwd_kernel(const void* __restrict__
     write_partials<VEC, MAXI, 2>(acc, lds, partials + (size_t)blockIdx.x * 2 * n, n, lane, wave);
 }
 
-// out[p][c] = sum_w partials[w][p][c]
+// out[p][c] = sum_w partials[w][p][c]; a workgroup owns 32 columns, 8 thread rows split the slabs, fixed order
 __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partials, float* __restrict__ o0,
                                                             float* __restrict__ o1, float* __restrict__ o2, int parts, int np,
                                                             int n) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= np * n) return;
+    __shared__ float red[8][33];
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const int total = np * n;
     float s = 0.0f;
-    for (int w = 0; w < parts; ++w) s += partials[(size_t)w * np * n + c];
-    const int p = c / n, cc = c % n;
-    float* o = p == 0 ? o0 : (p == 1 ? o1 : o2);
-    if (o) o[cc] = s;
+    if (c < total) {
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        int w = py;
+        for (; w + 24 < parts; w += 32) {
+            s0 += partials[(size_t)w * total + c];
+            s1 += partials[(size_t)(w + 8) * total + c];
+            s2 += partials[(size_t)(w + 16) * total + c];
+            s3 += partials[(size_t)(w + 24) * total + c];
+        }
+        for (; w < parts; w += 8) s0 += partials[(size_t)w * total + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[py][cx] = s;
+    __syncthreads();
+    if (py == 0 && c < total) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][cx];
+        const int p = c / n, cc = c % n;
+        float* o = p == 0 ? o0 : (p == 1 ? o1 : o2);
+        if (o) o[cc] = t;
+    }
 }
 
 struct RowCfg { int vec, maxi; };
@@ -371,15 +488,16 @@ inline bool pick_cfg(int n, RowCfg& c) {
 
 #define ROW_DISPATCH(cfg, KERNEL, grid, lds_bytes, st, ...)                                                    \
     do {                                                                                                       \
-        if (cfg.vec == 4 && cfg.maxi == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, dim3(256), lds_bytes, st, __VA_ARGS__);        \
-        else if (cfg.vec == 4 && cfg.maxi == 3) hipLaunchKernelGGL((KERNEL<4, 3>), grid, dim3(256), lds_bytes, st, __VA_ARGS__);   \
-        else if (cfg.vec == 4 && cfg.maxi == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(256), lds_bytes, st, __VA_ARGS__);   \
-        else if (cfg.vec == 4 && cfg.maxi == 12) hipLaunchKernelGGL((KERNEL<4, 12>), grid, dim3(256), lds_bytes, st, __VA_ARGS__); \
-        else if (cfg.vec == 4 && cfg.maxi == 16) hipLaunchKernelGGL((KERNEL<4, 16>), grid, dim3(256), lds_bytes, st, __VA_ARGS__); \
-        else hipLaunchKernelGGL((KERNEL<1, 16>), grid, dim3(256), lds_bytes, st, __VA_ARGS__);                  \
+        if (cfg.vec == 4 && cfg.maxi == 2) hipLaunchKernelGGL((KERNEL<4, 2>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);        \
+        else if (cfg.vec == 4 && cfg.maxi == 3) hipLaunchKernelGGL((KERNEL<4, 3>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);   \
+        else if (cfg.vec == 4 && cfg.maxi == 4) hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);   \
+        else if (cfg.vec == 4 && cfg.maxi == 12) hipLaunchKernelGGL((KERNEL<4, 12>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__); \
+        else if (cfg.vec == 4 && cfg.maxi == 16) hipLaunchKernelGGL((KERNEL<4, 16>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<1, 16>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);                  \
     } while (0)
 
 inline int check_dtype(int d) { return d == SPV_F32 || d == SPV_BF16; }
+inline int pool_mode_of(int n, int k_in) { return k_in == n ? POOL_IDENT : (k_in % n == 0 ? POOL_EXACT : POOL_TABLE); }
 
 }  // namespace
 
@@ -394,9 +512,13 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
     RowCfg cfg;
     SPV_CHECK(pick_cfg(n, cfg), "spv_spectre_tail_fwd: unsupported row length %d", n);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    dim3 grid(std::min(cdiv(rows, 4), 2048));
-    ROW_DISPATCH(cfg, tail_fwd_kernel, grid, 0, st, h, x, gamma, beta, out, mean, rstd, rows, n, k_in,
-                 dtype == SPV_BF16, out_dtype == SPV_BF16, p_drop, seed);
+    SPV_CHECK((int64_t)n * k_in < (1ll << 31), "spv_spectre_tail_fwd: n*k_in too large");
+    const int pm = pool_mode_of(n, k_in);
+    dim3 grid(std::min(cdiv(rows, RW), 2048));
+    const size_t lds_f = pm == POOL_TABLE ? ((size_t)2 * n + (size_t)RW * k_in) * sizeof(float) : 0;
+    SPV_CHECK(lds_f <= 64 * 1024, "spv_spectre_tail_fwd: n=%d k_in=%d needs %zu bytes of LDS", n, k_in, lds_f);
+    ROW_DISPATCH(cfg, tail_fwd_kernel, grid, lds_f, st, h, x, gamma, beta, out, mean,
+                 rstd, rows, n, k_in, dtype == SPV_BF16, out_dtype == SPV_BF16, p_drop, seed, pm);
     SPV_LAUNCH_CHECK("spv_spectre_tail_fwd");
     return 0;
 }
@@ -410,11 +532,15 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
     RowCfg cfg;
     SPV_CHECK(pick_cfg(n, cfg), "spv_spectre_tail_bwd: unsupported row length %d", n);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int wgs = std::min(cdiv(rows, 4), BWD_MAX_WG);
-    ROW_DISPATCH(cfg, tail_bwd_kernel, dim3(wgs), (size_t)3 * n * sizeof(float), st, dout, h, mean, rstd, gamma, beta, dh,
-                 dx_pool, partials, rows, n, k_in, dtype == SPV_BF16, dout_dtype == SPV_BF16, p_drop, seed);
+    SPV_CHECK((int64_t)n * k_in < (1ll << 31), "spv_spectre_tail_bwd: n*k_in too large");
+    const int pm = pool_mode_of(n, k_in);
+    const int wgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
+    const size_t lds = (size_t)3 * n * sizeof(float) + (pm == POOL_TABLE ? (size_t)(2 * k_in + n + RW * n) * sizeof(int) : 0);
+    SPV_CHECK(lds <= 64 * 1024, "spv_spectre_tail_bwd: n=%d k_in=%d needs %zu bytes of LDS", n, k_in, lds);
+    ROW_DISPATCH(cfg, tail_bwd_kernel, dim3(wgs), lds, st, dout, h, mean, rstd, gamma, beta, dh,
+                 dx_pool, partials, rows, n, k_in, dtype == SPV_BF16, dout_dtype == SPV_BF16, p_drop, seed, pm);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd");
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, 256)), dim3(256), 0, st, partials, dgamma, dbeta, dbias, wgs, 3, n);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, 32)), dim3(256), 0, st, partials, dgamma, dbeta, dbias, wgs, 3, n);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(fold)");
     return 0;
 }
@@ -427,7 +553,7 @@ extern "C" int spv_add_layernorm_fwd(const void* a, const void* b, const float* 
     RowCfg cfg;
     SPV_CHECK(pick_cfg(n, cfg), "spv_add_layernorm_fwd: unsupported row length %d", n);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    dim3 grid(std::min(cdiv(rows, 4), 2048));
+    dim3 grid(std::min(cdiv(rows, RW), 2048));
     ROW_DISPATCH(cfg, addln_fwd_kernel, grid, 0, st, a, b, gamma, beta, out, mean, rstd, rows, n, mode, dtype == SPV_BF16);
     SPV_LAUNCH_CHECK("spv_add_layernorm_fwd");
     return 0;
@@ -442,11 +568,11 @@ extern "C" int spv_add_layernorm_bwd(const void* dout, const void* a, const void
     RowCfg cfg;
     SPV_CHECK(pick_cfg(n, cfg), "spv_add_layernorm_bwd: unsupported row length %d", n);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int wgs = std::min(cdiv(rows, 4), BWD_MAX_WG);
+    const int wgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
     ROW_DISPATCH(cfg, addln_bwd_kernel, dim3(wgs), (size_t)2 * n * sizeof(float), st, dout, a, b, mean, rstd, gamma, din,
                  partials, rows, n, mode, dtype == SPV_BF16);
     SPV_LAUNCH_CHECK("spv_add_layernorm_bwd");
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(2 * n, 256)), dim3(256), 0, st, partials, dgamma, dbeta, (float*)nullptr, wgs, 2, n);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(2 * n, 32)), dim3(256), 0, st, partials, dgamma, dbeta, (float*)nullptr, wgs, 2, n);
     SPV_LAUNCH_CHECK("spv_add_layernorm_bwd(fold)");
     return 0;
 }
