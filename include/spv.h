@@ -60,6 +60,12 @@ int spv_gemm_nt_grouped_rows(const void* A, const void* B, const float* bias, co
                              int N, int K, int lda, int ldb, int ldc, int in_dtype, int out_dtype,
                              int rows_per_group, int group_stride, int row_offset, void* stream);
 
+/* TN contraction C[M,N] = sum_k A[k][m] B[k][n], A [K,lda>=M], B [K,ldb>=N] row-major bf16: the weight gradient
+ * dW = dh^T . x (backward of layers.py:86) straight from the row-major activations (transposing LDS reads,
+ * ds_read_b64_tr_b16); M, N, lda, ldb multiples of 8; split-K as above. */
+int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
+                int accumulate, int splits, void* workspace, void* stream);
+
 /* ---- SpectreLinear tail: out = dropout(GELU_erf(LayerNorm(h)) + adaptive_avg_pool(x)) ---------
  * spectre_vit/models/spectre/layers.py:85-101 (LN eps 1e-5, nn.GELU exact, AdaptiveAvgPool1d over the
  * channel axis; identity skip when k_in == n) + the nn.Dropout that follows it in

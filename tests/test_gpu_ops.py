@@ -68,6 +68,31 @@ def test_gemm_nt(ops, dtype, M, N, K, splits):
     check(C2, a @ b.T + c2, TOL[dtype], "gemm accumulate")
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(128, 128, 64, 1), (768, 512, 33280, 12), (104, 48, 1000, 3), (512, 8192, 2600, 2),
+                                          (8, 16, 40, 1), (264, 136, 4100, 5)])
+def test_gemm_tn(ops, M, N, K, splits):
+    """C = A^T B from row-major [K,M], [K,N] bf16 (ds_read_b64_tr_b16 fragments); asymmetric random operands."""
+    from spectre_vit import _native
+    rng = np.random.default_rng(M * 3 + N * 5 + K)
+    a = q(rng.standard_normal((K, M)), torch.bfloat16)
+    b = q(rng.standard_normal((K, N)) + 0.25, torch.bfloat16)
+    A, B = t(a, torch.bfloat16), t(b, torch.bfloat16)
+    C = torch.empty((M, N), dtype=torch.float32, device=dev())
+    ws = torch.empty((splits * M * N,), dtype=torch.float32, device=dev()) if splits > 1 else None
+    _native.call("spv_gemm_tn", A.data_ptr(), B.data_ptr(), C.data_ptr(), M, N, K, M, N, N, 0, 0, splits,
+                 0 if ws is None else ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    check(C, a.T @ b, 1e-4, "gemm_tn")
+    # identity check with asymmetric B: A = [I; 0] picks rows of B
+    Kp = 64
+    eye = np.zeros((Kp, 32)); eye[:32] = np.eye(32)
+    bb = q(rng.standard_normal((Kp, 40)), torch.bfloat16)
+    A2, B2 = t(eye, torch.bfloat16), t(bb, torch.bfloat16)
+    C2 = torch.empty((32, 40), dtype=torch.float32, device=dev())
+    _native.call("spv_gemm_tn", A2.data_ptr(), B2.data_ptr(), C2.data_ptr(), 32, 40, Kp, 32, 40, 40, 0, 0, 1, 0,
+                 torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(n64(C2), bb[:32]), "A = I must return B's rows exactly"
+
+
 def test_gemm_grouped_rows(ops):
     from spectre_vit import _native
     rng = np.random.default_rng(3)

@@ -92,6 +92,16 @@ def main():
         gemm(ROWS, 8192, E, acc=1)
         gemm(E, 8192, ROWS, True, 4)
 
+    def gemm_tn(M, N, K, splits):
+        A = torch.randn(K, M, device=dev).to(bf)
+        Bm = torch.randn(K, N, device=dev).to(bf)
+        C = torch.empty(M, N, device=dev)
+        ws = torch.empty(splits * M * N, device=dev)
+        cases.append((f"gemm_tn {M}x{N}x{K} splits={splits}", lambda: _native.call("spv_gemm_tn", p(A), p(Bm), p(C), M, N, K, M, N, N, 0, 0, splits, p(ws), st), None, 2.0 * M * N * K))
+
+    gemm_tn(F, E, ROWS, 12)
+    gemm_tn(E, F, ROWS, 12)
+    gemm_tn(F, E, ROWS, 42)
     t1 = torch.empty(F, ROWS, device=dev, dtype=bf)
     hh = torch.randn(ROWS, F, device=dev).to(bf)
     cases.append(("cast_transpose 33280x768 bf16", lambda: _native.call("spv_cast_transpose", p(hh), 1, p(t1), 1, ROWS, F, ROWS, 0, 0, 0, st), ROWS * F * 4, None))

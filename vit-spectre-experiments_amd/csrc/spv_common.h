@@ -93,14 +93,17 @@ __device__ __forceinline__ void gelu_fast(float x, float& g, float& dg) {
     dg = fmaf(x * u, 0.39894228040143267794f, phi);
 }
 
-// Counter-based dropout mask: keep(seed, element index) -- regenerated identically in the backward,
-// so no mask tensor is stored.  (The stream differs from torch's Philox; parity runs use p = 0.)
+// Counter-based dropout mask: keep(seed, row, col) -- regenerated identically in the backward, so no mask tensor is
+// stored.  (The stream differs from torch's Philox; parity runs use p = 0.)  A per-row key is hashed once; every
+// element costs one more 32-bit finaliser (murmur3-style) on key + col * golden.
 __device__ __forceinline__ unsigned mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
-    unsigned h = mix32((unsigned)idx ^ mix32((unsigned)(idx >> 32) + (unsigned)seed) ^ (unsigned)(seed >> 32) * 0x9e3779b9u);
-    float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-    return u < p ? 0.0f : inv_keep;
+__device__ __forceinline__ unsigned dropout_row_key(uint64_t seed, uint64_t row) {
+    return mix32((unsigned)seed + (unsigned)row * 0x9e3779b1u) ^ mix32((unsigned)(seed >> 32) + (unsigned)(row >> 32));
+}
+__device__ __forceinline__ float dropout_scale(unsigned row_key, unsigned col, float p, float inv_keep) {
+    const unsigned h = mix32(row_key + col * 0x9e3779b1u);
+    return (float)(h >> 8) * (1.0f / 16777216.0f) < p ? 0.0f : inv_keep;
 }

@@ -36,6 +36,106 @@ __device__ __forceinline__ int xcd_remap(int id, int nwg) {
     return base + (id >> 3);
 }
 
+// Epilogue shared by the NT and TN kernels: the accumulators go through a wave-private fp32 LDS stage
+// ([32 rows][64 + 4 pad]) so that every lane leaves with 8 CONSECUTIVE columns of one row: 16-byte (bf16) /
+// 2 x 16-byte (fp32) global stores, 8 rows x 128 B per wave instruction, instead of 64 two-byte stores per lane
+// (store-issue bound).  C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+template <typename TO>
+__device__ __forceinline__ void store_acc_tile(f32x16 (&acc)[2][2], unsigned char* smem, const float* __restrict__ bias,
+                                               TO* __restrict__ C, float* __restrict__ ws, int M, int N, int ldc, int accumulate,
+                                               int m0, int n0, int split, int rg, int gs, int roff,
+                                               const float* __restrict__ bias2d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, fh = lane >> 5;
+    float* stage = reinterpret_cast<float*>(smem + wave * 9216);  // 9216 B per wave >= 32 * 68 * 4
+    constexpr int SLD = 68;
+    const bool vec_c = ((size_t)ldc * sizeof(TO)) % 16 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+    const bool vec_ws = (N & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stage[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + j * 32 + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int qd = lane + 64 * t;
+            const int lr = qd >> 3, c8 = qd & 7;
+            const int row = m0 + wm * 64 + i * 32 + lr;
+            const int col0 = n0 + wn * 64 + c8 * 8;
+            if (row >= M || col0 >= N) continue;
+            float v[8];
+            {
+                const float4 lo = *reinterpret_cast<const float4*>(stage + lr * SLD + c8 * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(stage + lr * SLD + c8 * 8 + 4);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            }
+            const int nvalid = min(8, N - col0);
+            if (ws != nullptr) {
+                float* wp = ws + ((size_t)split * M + row) * N + col0;
+                if (nvalid == 8 && vec_ws) {
+                    *reinterpret_cast<float4*>(wp) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(wp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                    for (int u = 0; u < nvalid; ++u) wp[u] = v[u];
+                }
+                continue;
+            }
+            int orow = row;
+            const float* b2 = nullptr;
+            if (rg > 0) {  // grouped output rows (patch rows -> token rows, skipping each image's CLS row)
+                orow = (row / rg) * gs + roff + (row % rg);
+                if (bias2d) b2 = bias2d + (size_t)(row % rg) * N + col0;
+            }
+            TO* cp = C + (size_t)orow * ldc + col0;
+            if (nvalid == 8 && vec_c) {
+                if (bias != nullptr) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bias + col0), b1 = *reinterpret_cast<const float4*>(bias + col0 + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (b2 != nullptr) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] += b2[u];
+                }
+                if constexpr (sizeof(TO) == 2) {
+                    if (accumulate) {
+                        const uint4 old = *reinterpret_cast<const uint4*>(cp);
+                        v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                        v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                        v[4] += __uint_as_float(old.z << 16); v[5] += __uint_as_float(old.z & 0xffff0000u);
+                        v[6] += __uint_as_float(old.w << 16); v[7] += __uint_as_float(old.w & 0xffff0000u);
+                    }
+                    uint4 o;
+                    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+                    o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(cp) = o;
+                } else {
+                    float4* c4 = reinterpret_cast<float4*>(cp);
+                    if (accumulate) {
+                        const float4 o0 = c4[0], o1 = c4[1];
+                        v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
+                    }
+                    c4[0] = make_float4(v[0], v[1], v[2], v[3]);
+                    c4[1] = make_float4(v[4], v[5], v[6], v[7]);
+                }
+            } else {
+                for (int u = 0; u < nvalid; ++u) {
+                    float x = v[u];
+                    if (bias != nullptr) x += bias[col0 + u];
+                    if (b2 != nullptr) x += b2[u];
+                    if (accumulate) x += load_out<TO>(cp + u);
+                    store_out<TO>(cp + u, x);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, const T* __restrict__ B,
                                                       const float* __restrict__ bias, TO* __restrict__ C,
@@ -146,97 +246,105 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
         __syncthreads();
     }
 
-    // epilogue: the accumulators go through a wave-private fp32 LDS stage ([32 rows][64 + 4 pad]) so that every
-    // lane leaves with 8 CONSECUTIVE columns of one row: 16-byte (bf16) / 2 x 16-byte (fp32) global stores, 8 rows x
-    // 128 B per wave instruction, instead of 64 two-byte stores per lane (store-issue bound).
-    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
-    float* stage = reinterpret_cast<float*>(smem + wave * (BM * ROWB / 2));  // 9216 B per wave >= 32 * 68 * 4
-    constexpr int SLD = 68;
-    const bool vec_c = ((size_t)ldc * sizeof(TO)) % 16 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
-    const bool vec_ws = (N & 3) == 0;
+    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// TN contraction: C[M,N] = sum_k A[k][m] * B[k][n]  with A [K, lda>=M] and B [K, ldb>=N] row-major (bf16).
+// This is the weight gradient dW = dh^T . x taken straight from the row-major activations: no transposed copies.
+// Tiles are staged in LDS exactly as they lie in memory ([k][m] rows of 256 B + 64 B pad, coalesced 16-byte loads);
+// the MFMA fragments (8 consecutive k for one m / one n per lane) come out of ds_read_b64_tr_b16, the gfx950
+// transposing LDS read: per 16-lane group it reads a 4 (k) x 16 (m) block and hands lane i column i.  With the
+// 320-byte row stride the four k rows of a group land in four disjoint 16-bank ranges (conflict free).
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+constexpr int TROWB = 256 + 64;  // LDS bytes per k row (128 bf16 + pad)
+constexpr int TBK = 32;          // k rows per stage
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
+    // base: this lane's address for rows k0..k0+3; the second read covers rows k0+4..k0+7
+    using lds_ptr = s16x4 __attribute__((address_space(3)))*;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + 4 * TROWB));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                      TO* __restrict__ C, float* __restrict__ ws, int M, int N, int K, int lda,
+                                                      int ldb, int ldc, int k_per_split, int accumulate, int tiles_n,
+                                                      int tiles_mn) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * ROWB];  // 36 864 B >= 2 * TBK * TROWB = 20 480 B
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + TBK * TROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int split = blockIdx.y;
+    const int tile = xcd_remap(blockIdx.x, tiles_mn);
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+
+    // staging map: TBK = 32 k rows x 16 chunks of 16 B per operand = 512 chunks -> 2 per thread per operand
+    const int srow = tid >> 4, sch = tid & 15;  // rows srow, srow + 16
+    const bool a_ok = (m0 + sch * 8) < M, b_ok = (n0 + sch * 8) < N;  // M, N multiples of 8: a chunk is all in or all out
+    uint4 ra[2], rb[2];
+    auto load_tile = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        __syncthreads();
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + srow + 16 * i;
+            const bool kin = k < kend;
+            ra[i] = (kin && a_ok) ? *reinterpret_cast<const uint4*>(A + (size_t)k * lda + m0 + sch * 8) : make_uint4(0, 0, 0, 0);
+            rb[i] = (kin && b_ok) ? *reinterpret_cast<const uint4*>(B + (size_t)k * ldb + n0 + sch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<uint4*>(sA + (srow + 16 * i) * TROWB + sch * 16) = ra[i];
+            *reinterpret_cast<uint4*>(sB + (srow + 16 * i) * TROWB + sch * 16) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stage[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + j * 32 + (lane & 31)] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // transposing-read lane geometry: 16-lane group g = lane >> 4 covers columns 16 (g & 1) + [0,16) of the 32-wide
+    // MFMA block and k half h = g >> 1; inside the group lane 4 q + p supplies row q, columns 4 p .. 4 p + 3
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int frag_off = (8 * (g >> 1) + q) * TROWB + (16 * (g & 1) + 4 * pp) * 2;
+    const unsigned char* fa0 = sA + frag_off + (wm * 64) * 2;
+    const unsigned char* fb0 = sB + frag_off + (wn * 64) * 2;
+
+    load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += TBK) {
+        store_tile();
         __syncthreads();
+        if (k0 + TBK < kend) load_tile(k0 + TBK);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int qd = lane + 64 * t;
-            const int lr = qd >> 3, c8 = qd & 7;
-            const int row = m0 + wm * 64 + i * 32 + lr;
-            const int col0 = n0 + wn * 64 + c8 * 8;
-            if (row >= M || col0 >= N) continue;
-            float v[8];
-            {
-                const float4 lo = *reinterpret_cast<const float4*>(stage + lr * SLD + c8 * 8);
-                const float4 hi = *reinterpret_cast<const float4*>(stage + lr * SLD + c8 * 8 + 4);
-                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
-            }
-            const int nvalid = min(8, N - col0);
-            if (ws != nullptr) {
-                float* wp = ws + ((size_t)split * M + row) * N + col0;
-                if (nvalid == 8 && vec_ws) {
-                    *reinterpret_cast<float4*>(wp) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(wp + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                } else {
-                    for (int u = 0; u < nvalid; ++u) wp[u] = v[u];
-                }
-                continue;
-            }
-            int orow = row;
-            const float* b2 = nullptr;
-            if (rg > 0) {  // grouped output rows (patch rows -> token rows, skipping each image's CLS row)
-                orow = (row / rg) * gs + roff + (row % rg);
-                if (bias2d) b2 = bias2d + (size_t)(row % rg) * N + col0;
-            }
-            TO* cp = C + (size_t)orow * ldc + col0;
-            if (nvalid == 8 && vec_c) {
-                if (bias != nullptr) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(bias + col0), b1 = *reinterpret_cast<const float4*>(bias + col0 + 4);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                }
-                if (b2 != nullptr) {
+        for (int ks = 0; ks < TBK / 16; ++ks) {
+            bf16x8 a[2], b[2];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] += b2[u];
-                }
-                if constexpr (sizeof(TO) == 2) {
-                    if (accumulate) {
-                        const uint4 old = *reinterpret_cast<const uint4*>(cp);
-                        v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-                        v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
-                        v[4] += __uint_as_float(old.z << 16); v[5] += __uint_as_float(old.z & 0xffff0000u);
-                        v[6] += __uint_as_float(old.w << 16); v[7] += __uint_as_float(old.w & 0xffff0000u);
-                    }
-                    uint4 o;
-                    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                    o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                    o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-                    o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
-                    *reinterpret_cast<uint4*>(cp) = o;
-                } else {
-                    float4* c4 = reinterpret_cast<float4*>(cp);
-                    if (accumulate) {
-                        const float4 o0 = c4[0], o1 = c4[1];
-                        v[0] += o0.x; v[1] += o0.y; v[2] += o0.z; v[3] += o0.w; v[4] += o1.x; v[5] += o1.y; v[6] += o1.z; v[7] += o1.w;
-                    }
-                    c4[0] = make_float4(v[0], v[1], v[2], v[3]);
-                    c4[1] = make_float4(v[4], v[5], v[6], v[7]);
-                }
-            } else {
-                for (int u = 0; u < nvalid; ++u) {
-                    float x = v[u];
-                    if (bias != nullptr) x += bias[col0 + u];
-                    if (b2 != nullptr) x += b2[u];
-                    if (accumulate) x += load_out<TO>(cp + u);
-                    store_out<TO>(cp + u, x);
-                }
+            for (int f = 0; f < 2; ++f) {
+                a[f] = tr_frag(fa0 + ks * 16 * TROWB + f * 64);
+                b[f] = tr_frag(fb0 + ks * 16 * TROWB + f * 64);
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        __syncthreads();
     }
+    store_acc_tile<TO>(acc, smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr);
 }
 
 template <typename TO>
@@ -325,3 +433,42 @@ static int gemm_entry(const void* A, const void* B, const float* bias, void* C, 
         return launch_gemm<float, bf16_t>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d);
     return launch_gemm<float, float>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d);
 }
+
+extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
+                           int accumulate, int splits, void* workspace, void* stream) {
+    SPV_CHECK(M > 0 && N > 0 && K > 0, "spv_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
+    SPV_CHECK(out_dtype == SPV_F32 || out_dtype == SPV_BF16, "spv_gemm_tn: bad out_dtype %d", out_dtype);
+    SPV_CHECK(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0,
+              "spv_gemm_tn: M=%d N=%d lda=%d ldb=%d must be multiples of 8 (bf16, 16-byte chunks)", M, N, lda, ldb);
+    SPV_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "spv_gemm_tn: A/B must be 16-byte aligned");
+    SPV_CHECK(lda >= M && ldb >= N && ldc >= N, "spv_gemm_tn: leading dimension too small");
+    SPV_CHECK(splits >= 1 && (splits == 1 || workspace != nullptr), "spv_gemm_tn: split-K needs a workspace");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+    int k_per_split = K;
+    if (splits > 1) {
+        k_per_split = cdiv(cdiv(K, splits), TBK) * TBK;
+        splits = cdiv(K, k_per_split);
+    }
+    float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
+    dim3 grid(tiles_m * tiles_n, splits);
+    if (out_dtype == SPV_BF16)
+        hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, ws, M, N,
+                           K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (float*)C, ws, M, N, K,
+                           lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n);
+    SPV_LAUNCH_CHECK("spv_gemm_tn");
+    if (splits > 1) {
+        int blocks = (int)std::min<int64_t>(((int64_t)M * N + 255) / 256, 2048);
+        if (out_dtype == SPV_BF16)
+            hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, (const float*)nullptr, (bf16_t*)C, M, N,
+                               ldc, splits, accumulate);
+        else
+            hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(blocks), dim3(256), 0, st, ws, (const float*)nullptr, (float*)C, M, N, ldc,
+                               splits, accumulate);
+        SPV_LAUNCH_CHECK("spv_gemm_tn(split-k reduce)");
+    }
+    return 0;
+}
+

@@ -87,11 +87,21 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
 }
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partials, float* __restrict__ out, int parts,
                                                           int n) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
+    // a workgroup owns 32 columns; 8 thread rows split the partial slabs; fixed summation order
+    __shared__ float red[8][33];
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     float s = 0.0f;
-    for (int p = 0; p < parts; ++p) s += partials[(size_t)p * n + c];
-    out[c] = s;
+    if (c < n)
+        for (int p = py; p < parts; p += 8) s += partials[(size_t)p * n + c];
+    red[py][cx] = s;
+    __syncthreads();
+    if (py == 0 && c < n) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][cx];
+        out[c] = t;
+    }
 }
 
 inline int ew_blocks(int64_t n) { return (int)std::min<int64_t>((n + 255) / 256, 2048); }
@@ -176,7 +186,7 @@ extern "C" int spv_colsum(const void* x, float* out, float* partials, int rows, 
     DISPATCH_T(dtype, "spv_colsum",
                hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(parts), dim3(256), 0, st, (const T*)x, partials, rows, n));
     SPV_LAUNCH_CHECK("spv_colsum");
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, partials, out, parts, n);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(n, 32)), dim3(256), 0, st, partials, out, parts, n);
     SPV_LAUNCH_CHECK("spv_colsum(fold)");
     return 0;
 }

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ x
                                                       uint64_t seed, int bf) {
     const float inv_keep = 1.0f / (1.0f - p);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        st_any(y, (size_t)i, bf, ld_any(x, (size_t)i, bf) * dropout_scale(seed, (uint64_t)i, p, inv_keep));
+        st_any(y, (size_t)i, bf, ld_any(x, (size_t)i, bf) *
+                                     dropout_scale(dropout_row_key(seed, (uint64_t)i >> 12), (unsigned)(i & 4095), p, inv_keep));
 }
 
 __device__ __forceinline__ float rcoef(int u, int v, int p, int q, int P) {

@@ -36,6 +36,10 @@ template <> __device__ __forceinline__ void stv<1>(void* base, size_t off, int b
     if (bf) static_cast<bf16_t*>(base)[off] = f2bf(v[0]);
     else static_cast<float*>(base)[off] = v[0];
 }
+// Same-wave LDS hand-off (one lane writes, another lane of the SAME wave reads): the LDS pipe is in order per wave,
+// so only the compiler must be kept from reordering; waiting on lgkmcnt alone leaves global loads/stores in flight
+// (a workgroup-scope fence would also drain vmcnt, i.e. wait for the previous row's stores every row).
+__device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ float ld1(const void* base, size_t off, int bf) {
     return bf ? bf2f(static_cast<const bf16_t*>(base)[off]) : static_cast<const float*>(base)[off];
 }
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h
         float mean, rstd;
         row_stats<VEC, MAXI>(hv, n, lane, mean, rstd);
         if (pool_mode == POOL_TABLE) {
-            __threadfence_block();  // previous row's pooled reads are done before the stage is overwritten
+            lds_fence();  // previous row's pooled reads are done before the stage is overwritten
             if ((k_in & 3) == 0) {
                 for (int j = lane * 4; j < k_in; j += 256) {
                     float t4[4];
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h
             } else {
                 for (int j = lane; j < k_in; j += 64) xs[j] = ld1(x, (size_t)row * k_in + j, bf);
             }
-            __threadfence_block();  // same-wave LDS traffic is in order; the fence keeps the compiler from reordering
+            lds_fence();  // same-wave LDS traffic is in order; the fence keeps the compiler from reordering
         }
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(RT) void tail_bwd_kernel(const void* __restrict__ d
             }
         }
         const float m1 = wave_sum(s1) / (float)n, m2 = wave_sum(s2) / (float)n;
-        if (pool_mode == POOL_TABLE) __threadfence_block();
+        if (pool_mode == POOL_TABLE) lds_fence();
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int e0 = (i * 64 + lane) * VEC;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(RT) void tail_bwd_kernel(const void* __restrict__ d
                 for (int c = c_lo; c <= c_hi; ++c) a += ds[c] * inv_w_t[c];
                 st1(dxp, (size_t)row * k_in + j, bf, a);
             }
-            __threadfence_block();  // pooled reads done before the next row overwrites the stage
+            lds_fence();  // pooled reads done before the next row overwrites the stage
         }
     }
     write_partials<VEC, MAXI, 3>(acc, lds, partials + (size_t)blockIdx.x * 3 * n, n, lane, wave);

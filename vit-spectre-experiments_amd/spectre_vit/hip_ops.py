@@ -201,18 +201,27 @@ def _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, 
 
 
 def _weight_grad(dh, x, rows, n, k):
-    """dW[n,k] = dh[rows,n]^T . x[rows,k] as an NT GEMM over row-major transposes, split-K over rows."""
+    """dW[n,k] = dh[rows,n]^T . x[rows,k], split-K over rows.  bf16: TN kernel straight from the row-major activations
+    (transposing LDS reads); fp32 (parity path): NT kernel over explicit transposes."""
     dev = dh.device
+    dw = torch.empty((n, k), dtype=torch.float32, device=dev)
+    tiles = ((n + 127) // 128) * ((k + 127) // 128)
+    splits = max(1, min(1024 // tiles, (rows + 511) // 512))
+    ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev) if splits > 1 else None
+    if dh.dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0:
+        def launch():
+            _native.call("spv_gemm_tn", _p(dh), _p(x), _p(dw), n, k, rows, n, k, k, F32, 0, splits, _p(ws), _stream())
+        if _timer is not None:
+            _timer.bracket("gemm", (n, k, rows, BF16), launch)
+        else:
+            launch()
+        return dw
     ld = (rows + 7) // 8 * 8
     dht = torch.empty((n, ld), dtype=dh.dtype, device=dev)
     xt = torch.empty((k, ld), dtype=x.dtype, device=dev)
     st = _stream()
     _native.call("spv_cast_transpose", _p(dh), _dt(dh), _p(dht), _dt(dht), rows, n, ld, 0, 0, 0, st)
     _native.call("spv_cast_transpose", _p(x), _dt(x), _p(xt), _dt(xt), rows, k, ld, 0, 0, 0, st)
-    dw = torch.empty((n, k), dtype=torch.float32, device=dev)
-    tiles = ((n + 127) // 128) * ((k + 127) // 128)
-    splits = max(1, min(1024 // tiles, (ld + 511) // 512))
-    ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev) if splits > 1 else None
     _gemm(dht, xt, None, dw, n, k, ld, ld, ld, k, 0, splits, ws)
     return dw
 
