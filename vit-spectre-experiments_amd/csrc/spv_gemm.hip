@@ -13,6 +13,8 @@
 // (exact fp32 fma chain -- the parity path).
 #include "spv_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -250,6 +252,103 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// NT contraction, direct-to-LDS variant (bf16, K and the split-K slices multiples of 64): the same 128 x 128 x 64
+// tile, but the operands are staged with global_load_lds_dwordx4 (no staging VGPRs, one 1-KiB LDS burst per wave
+// instruction = 8 tile rows) into TWO LDS buffers, so the loads of K-step t+1 fly while the MFMAs of step t run
+// and one barrier per step is enough.  LDS-DMA writes are lane-linear, so the tile rows cannot be padded; bank
+// conflicts are removed by an XOR swizzle of the 16-byte chunk index with (row >> 1) & 7, applied on the per-lane
+// SOURCE address and again on the fragment read (guide rule 21): the 16 rows a ds_read_b128 lane group touches then
+// fall on 8 chunk positions x 2 row parities = all 64 banks.
+constexpr int GBK = 64;  // split-K slices of the direct-to-LDS kernel are multiples of this many bf16 elements
+
+// KB = bytes of K per tile row per stage: 128 (64 bf16, 2 x 32 KiB stages, 2 workgroups per CU: long-K problems) or
+// 64 (32 bf16, 2 x 16 KiB stages, 4 workgroups per CU: the skinny K = 512..768 layer GEMMs, which are bound by load
+// latency per K-step rather than by MFMA issue and want more independent tiles in flight per CU).
+template <typename TO, int KB>
+__global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                           const float* __restrict__ bias, TO* __restrict__ C,
+                                                           float* __restrict__ ws, int M, int N, int K, int lda, int ldb,
+                                                           int ldc, int k_per_split, int accumulate, int tiles_n,
+                                                           int tiles_mn, int rg, int gs, int roff,
+                                                           const float* __restrict__ bias2d) {
+    constexpr int CPR = KB / 16;              // 16-byte chunks per tile row
+    constexpr int RPI = 64 / CPR;             // tile rows written by one wave instruction (1 KiB)
+    constexpr int IPW = (BM / RPI) / 4;       // DMA instructions per wave per operand per stage
+    constexpr int STAGE = (BM + BN) * KB;     // bytes per stage
+    constexpr int KE = KB / 2;                // bf16 elements of K per stage
+    constexpr int SM = 2 * STAGE > 36864 ? 2 * STAGE : 36864;  // the epilogue stage needs 36 KiB
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int split = blockIdx.y;
+    const int tile = xcd_remap(blockIdx.x, tiles_mn);
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    auto swizzle = [](int R) { return CPR == 8 ? ((R >> 1) & 7) : ((R >> 2) & 3); };
+
+    // per-lane source pointers of this wave's IPW + IPW DMA instructions per stage
+    const bf16_t* asrc[IPW];
+    const bf16_t* bsrc[IPW];
+#pragma unroll
+    for (int t = 0; t < IPW; ++t) {
+        const int R = RPI * (wave * IPW + t) + lane / CPR;     // tile row written by this lane
+        const int c = (lane % CPR) ^ swizzle(R);                // logical 16-byte chunk that belongs at this LDS position
+        asrc[t] = A + (size_t)min(m0 + R, M - 1) * lda + c * 8;
+        bsrc[t] = B + (size_t)min(n0 + R, N - 1) * ldb + c * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+        unsigned char* sa = smem + buf * STAGE + wave * IPW * 1024;  // this wave's rows of the A tile
+        unsigned char* sb = sa + BM * KB;
+#pragma unroll
+        for (int t = 0; t < IPW; ++t) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[t] + k0),
+                                             (__attribute__((address_space(3))) void*)(sa + t * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[t] + k0),
+                                             (__attribute__((address_space(3))) void*)(sb + t * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int frow = lane & 31, fh = lane >> 5, swz = swizzle(frow);  // 64-row / 32-row offsets do not change the swizzle
+    const int fa_off = (wm * 64 + frow) * KB, fb_off = BM * KB + (wn * 64 + frow) * KB;
+
+    stage(0, kbeg);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += KE, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage `buf` has landed
+        __builtin_amdgcn_s_barrier();                     // everyone's has; everyone is done reading stage buf^1
+        if (k0 + KE < kend) stage(buf ^ 1, k0 + KE);
+        const unsigned char* sa = smem + buf * STAGE + fa_off;
+        const unsigned char* sb = smem + buf * STAGE + fb_off;
+#pragma unroll
+        for (int ks = 0; ks < KB / 32; ++ks) {
+            const int ch = ((ks * 2 + fh) ^ swz) * 16;
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f] = *reinterpret_cast<const bf16x8*>(sa + f * 32 * KB + ch);
+                b[f] = *reinterpret_cast<const bf16x8*>(sb + f * 32 * KB + ch);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // TN contraction: C[M,N] = sum_k A[k][m] * B[k][n]  with A [K, lda>=M] and B [K, ldb>=N] row-major (bf16).
 // This is the weight gradient dW = dh^T . x taken straight from the row-major activations: no transposed copies.
 // Tiles are staged in LDS exactly as they lie in memory ([k][m] rows of 256 B + 64 B pad, coalesced 16-byte loads);
@@ -363,6 +462,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+inline int kend_len(int K, int k_per_split) { return K < k_per_split ? K : k_per_split; }
+
 template <typename T, typename TO>
 int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb,
                 int ldc, int accumulate, int splits, void* workspace, hipStream_t st, int rg = 0, int gs = 0, int roff = 0,
@@ -376,10 +477,27 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
     }
     float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
     dim3 grid(tiles_m * tiles_n, splits);
+    if constexpr (sizeof(T) == 2) {
+        if (K % GBK == 0 && k_per_split % GBK == 0 && M >= 8 && N >= 8) {
+            static const int force_kb = getenv("SPV_GEMM_KB") ? atoi(getenv("SPV_GEMM_KB")) : 0;  // tuning aid
+            const int kb = force_kb ? force_kb : ((kend_len(K, k_per_split) <= 1024) ? 64 : 128);
+            if (kb == 64)
+                hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 64>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
+                                   static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
+                                   accumulate, tiles_n, tiles_m * tiles_n, rg, gs, roff, bias2d);
+            else
+                hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 128>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
+                                   static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
+                                   accumulate, tiles_n, tiles_m * tiles_n, rg, gs, roff, bias2d);
+            SPV_LAUNCH_CHECK("spv_gemm_nt(glds)");
+            goto reduce;
+        }
+    }
     hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), grid, dim3(256), 0, st, static_cast<const T*>(A),
                        static_cast<const T*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
                        accumulate, tiles_n, tiles_m * tiles_n, rg, gs, roff, bias2d);
     SPV_LAUNCH_CHECK("spv_gemm_nt");
+reduce:
     if (splits > 1) {
         int blocks = (int)std::min<int64_t>(((int64_t)M * N + 255) / 256, 2048);
         hipLaunchKernelGGL((splitk_reduce_kernel<TO>), dim3(blocks), dim3(256), 0, st, ws, bias, static_cast<TO*>(C), M,

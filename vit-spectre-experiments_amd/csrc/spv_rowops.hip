@@ -123,6 +123,8 @@ __global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h
     const float inv_pw = 1.0f / (float)(pw > 0 ? pw : 1);
     const int lane = threadIdx.x & 63;
     float* xs = lds + 2 * n + (threadIdx.x >> 6) * k_in;  // POOL_TABLE: this wave's fp32 copy of the input row
+    const bool exact4 = pool_mode == POOL_EXACT && (pw & 3) == 0 && VEC == 4;
+    float* xq = lds + (threadIdx.x >> 6) * (k_in >> 2);   // POOL_EXACT (pw % 4 == 0): per-wave sums of 4 inputs
     const int wave_g = blockIdx.x * RW + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * RW;
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
@@ -139,6 +141,16 @@ __global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h
         }
         float mean, rstd;
         row_stats<VEC, MAXI>(hv, n, lane, mean, rstd);
+        if (exact4) {
+            // coalesced pass over the input row: lane sums 4 consecutive inputs; the owner of an output adds pw/4 of them
+            lds_fence();
+            for (int qd = lane; qd < (k_in >> 2); qd += 64) {
+                float t4[4];
+                ldv<4>(x, (size_t)row * k_in + 4 * qd, bf, t4);
+                xq[qd] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+            }
+            lds_fence();
+        }
         if (pool_mode == POOL_TABLE) {
             lds_fence();  // previous row's pooled reads are done before the stage is overwritten
             if ((k_in & 3) == 0) {
@@ -167,13 +179,9 @@ __global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     float acc = 0.0f;
-                    if (VEC == 4 && (pw & 3) == 0) {
-                        for (int j = 0; j < pw; j += 4) {
-                            float t4[VEC];
-                            ldv<VEC>(x, xb + (size_t)k * pw + j, bf, t4);
-#pragma unroll
-                            for (int u = 0; u < VEC; ++u) acc += t4[u];
-                        }
+                    if (exact4) {
+                        const int q0 = (e0 + k) * (pw >> 2);
+                        for (int j = 0; j < (pw >> 2); ++j) acc += xq[q0 + j];
                     } else {
                         for (int j = 0; j < pw; ++j) acc += ld1(x, xb + (size_t)k * pw + j, bf);
                     }
@@ -519,7 +527,8 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
     SPV_CHECK((int64_t)n * k_in < (1ll << 31), "spv_spectre_tail_fwd: n*k_in too large");
     const int pm = pool_mode_of(n, k_in);
     dim3 grid(std::min(cdiv(rows, RW), 2048));
-    const size_t lds_f = pm == POOL_TABLE ? ((size_t)2 * n + (size_t)RW * k_in) * sizeof(float) : 0;
+    const size_t lds_f = pm == POOL_TABLE ? ((size_t)2 * n + (size_t)RW * k_in) * sizeof(float)
+                         : (pm == POOL_EXACT && (k_in / n) % 4 == 0 ? (size_t)RW * (k_in / 4) * sizeof(float) : 0);
     SPV_CHECK(lds_f <= 64 * 1024, "spv_spectre_tail_fwd: n=%d k_in=%d needs %zu bytes of LDS", n, k_in, lds_f);
     ROW_DISPATCH(cfg, tail_fwd_kernel, grid, lds_f, st, h, x, gamma, beta, out, mean,
                  rstd, rows, n, k_in, dtype == SPV_BF16, out_dtype == SPV_BF16, p_drop, seed, pm);
