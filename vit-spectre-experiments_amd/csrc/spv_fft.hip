@@ -12,6 +12,8 @@
 #include "spv_common.h"
 #include "spv_fft_core.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int FT = 512;  // threads per workgroup of the fast path
@@ -61,7 +63,8 @@ template <int MH>
 __global__ __launch_bounds__(FT) void fnet_lds_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                       const float* __restrict__ tw2, int N, int D, int log2tpf, FftPlan plan,
                                                       int bf) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds_f32[];
+    float* lds = lds_f32;
     float* twr = lds + (size_t)(N + 1) * D;
     float* twi = twr + D;
     const int tid = threadIdx.x;
@@ -157,10 +160,285 @@ __global__ __launch_bounds__(FT) void fnet_lds_kernel(const void* __restrict__ x
     }
 }
 
+// ---------------- v2: bf16, dim = 512 -- the benchmark shape (B, 65, 512) ------------------------------------
+// Two 512-thread workgroups per CU (LDS 72 KB each, everything bf16 in LDS, fp32 in registers):
+//   A  coalesced 16-byte loads -> LDS rows (row stride 1024 + 64 B)
+//   B  33 in-place radix-8 Stockham FFTs (two real rows per FFT), 64 threads each, twiddles in registers
+//   C  token-axis DFT + spectrum unpacking as ONE pair of matrix products on the MFMA pipe:
+//      Y1 = W1 . Z, Y2 = W2 . Z  (W: 32 x 80 bf16 per table, Z: the 66 planar FFT rows, fragments by
+//      ds_read_b64_tr_b16 straight from the row-major tile), rows m >= 32 on the VALU with fp32 weights
+//   D  y[m,k] = Y1[m,k] + Y2[m,D-k],  y[N-m,k] = Y1[m,D-k] + Y2[m,k] from a bf16 LDS stage, 16-byte stores.
+// Formulation and bf16 error budget are checked on the host (tests/cpu_harness/fnet_v2_test.cpp).
+// Diagnostic stamps (tools/fnet_stamps.hip defines SPV_FNET_STAMPS and provides the buffer); compiled out of the library.
+#ifdef SPV_FNET_STAMPS
+__device__ unsigned long long* g_fnet_stamps = nullptr;
+#define V2_STAMP(i)                                                                                  \
+    do {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+        if (g_fnet_stamps && (threadIdx.x & 63) == 0)                                                \
+            g_fnet_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                           \
+    } while (0)
+#else
+#define V2_STAMP(i)
+#endif
+constexpr int V2D = 512;
+constexpr int V2RS = V2D * 2 + 128;  // LDS row stride in bytes: 16 B of padding after every 64 elements, so that the
+                                     // radix-8 pass with Ns = 8 (stores 128 B apart across lanes) is bank-conflict free
+__device__ __forceinline__ int v2_off(int idx) { return 2 * idx + 16 * (idx >> 6); }  // byte offset of element idx in a row
+constexpr int V2KS = 5;              // MFMA k-steps: 80 >= 2 * ceil(79 / 2) planar rows
+constexpr int V2XR = 8;              // at most 8 rows m in [32, 40) go through the VALU path
+typedef __attribute__((ext_vector_type(4))) short v2s16x4;
+typedef __attribute__((ext_vector_type(8))) short v2s16x8;
+
+__global__ __launch_bounds__(256) void fnet_v2_table_kernel(bf16_t* __restrict__ frag, float* __restrict__ extra,
+                                                            float* __restrict__ tw, int N) {
+    // FFT twiddles of butterfly j = 2 t32: [t32][14][2]: r = 1..7 of pass 1 (Ns = 8), then r = 1..7 of pass 2 (Ns = 64)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 32 * 14; i += gridDim.x * blockDim.x) {
+        const int t32 = i / 14, q = i % 14, r = (q % 7) + 1, j = 2 * t32;
+        float sn, cs;
+        if (q < 7) sincospif(-2.0f * (float)(r * (j & 7)) / 64.0f, &sn, &cs);
+        else sincospif(-2.0f * (float)(r * j) / 512.0f, &sn, &cs);
+        tw[2 * i] = cs;
+        tw[2 * i + 1] = sn;
+    }
+    const int nh1 = N / 2 + 1;
+    auto weight = [&](int t, int m, int j) -> float {
+        if (m >= nh1 || j >= 2 * ((N + 1) / 2)) return 0.0f;
+        const int n1 = j & ~1, n2 = n1 + 1;
+        float c1 = 0.f, s1 = 0.f, c2 = 0.f, s2 = 0.f;
+        if (n1 < N) sincospif(2.0f * (float)(((long long)m * n1) % N) / (float)N, &s1, &c1);
+        if (n2 < N) sincospif(2.0f * (float)(((long long)m * n2) % N) / (float)N, &s2, &c2);
+        float w1r, w1i, w2r, w2i;
+        fnet_v2_weights(c1, s1, c2, s2, w1r, w1i, w2r, w2i);
+        return t == 0 ? ((j & 1) ? w1i : w1r) : ((j & 1) ? w2i : w2r);
+    };
+    const int nfrag = 2 * V2KS * 64 * 8;
+    const int nextra = V2XR * 2 * 16 * V2KS;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfrag + nextra; i += gridDim.x * blockDim.x) {
+        if (i < nfrag) {
+            // A-operand fragment order of v_mfma_f32_32x32x16_bf16: lane l holds W[m = l & 31][j = 16 ks + 8 (l >> 5) + e]
+            const int e = i & 7, l = (i >> 3) & 63, ks = (i >> 9) % V2KS, t = i / (V2KS * 512);
+            frag[i] = f2bf(weight(t, l & 31, 16 * ks + 8 * (l >> 5) + e));
+        } else {
+            const int q = i - nfrag;
+            const int j = q % (16 * V2KS), t = (q / (16 * V2KS)) & 1, me = q / (2 * 16 * V2KS);
+            extra[q] = weight(t, 32 + me, j);
+        }
+    }
+}
+
+__device__ __forceinline__ float v2_ld(const bf16_t* p) { return bf2f(*p); }
+
+// exp(-2 pi i r / 64) and exp(-2 pi i r / 512), r = 1..7: the step from butterfly j to j + 1 in passes 1 and 2
+__device__ constexpr float V2ROT1[7][2] = {{0.995184727f, -0.0980171403f}, {0.98078528f, -0.195090322f}, {0.956940336f, -0.290284677f}, {0.923879533f, -0.382683432f}, {0.881921264f, -0.471396737f}, {0.831469612f, -0.555570233f}, {0.773010453f, -0.634393284f}};
+__device__ constexpr float V2ROT2[7][2] = {{0.999924702f, -0.0122715383f}, {0.999698819f, -0.0245412285f}, {0.999322385f, -0.0368072229f}, {0.998795456f, -0.0490676743f}, {0.998118113f, -0.0613207363f}, {0.997290457f, -0.0735645636f}, {0.996312612f, -0.0857973123f}};
+
+// One radix-8 Stockham pass (sub-transform length 2^LGNS) over one row pair, TWO butterflies per thread
+// (j = 2 t32, 2 t32 + 1; 32 threads per FFT): adjacent butterflies read and write adjacent bf16 elements, so every
+// LDS access moves a packed pair (ds_read/write_b32), and pass 0's eight outputs of a butterfly are contiguous
+// (one ds_write_b128 per component).  2.3x fewer LDS instructions than one 16-bit access per element.
+// An FFT's 32 threads are one half of ONE wave, and a wave's LDS instructions execute in order: the read phase of
+// a pass is complete before the same wave's write phase issues, so no workgroup barrier is needed inside phase B --
+// only a compiler fence (plus the lgkmcnt wait that makes the loaded registers valid anyway).
+__device__ __forceinline__ void v2_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+typedef float v2f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned v2_pack(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+template <int LGNS>
+__device__ __forceinline__ void v2_pass(unsigned char* re, unsigned char* im, int t32, const cpx (&tw)[7], bool active) {
+    constexpr int NS = 1 << LGNS;
+    cpx_t<v2f2> v[8];  // component [u] = butterfly j = 2 t32 + u: the whole butterfly runs on packed v_pk_*_f32 math
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const unsigned pr = *reinterpret_cast<const unsigned*>(re + 4 * t32 + 144 * r);  // v2_off(2 t32 + 64 r)
+            const unsigned pi = *reinterpret_cast<const unsigned*>(im + 4 * t32 + 144 * r);
+            cpx_t<v2f2> xv;
+            xv.re = v2f2{__uint_as_float(pr << 16), __uint_as_float(pr & 0xffff0000u)};
+            xv.im = v2f2{__uint_as_float(pi << 16), __uint_as_float(pi & 0xffff0000u)};
+            if (LGNS == 0 || r == 0) {
+                v[r] = xv;
+            } else {
+                // butterfly 2 t32 + 1 uses the twiddle of 2 t32 advanced by a compile-time rotation (saves 28 VGPRs)
+                const cpx rot = LGNS == 3 ? cmk(V2ROT1[r - 1][0], V2ROT1[r - 1][1]) : cmk(V2ROT2[r - 1][0], V2ROT2[r - 1][1]);
+                cpx t = tw[r - 1];
+                asm volatile("" : "+v"(t.re), "+v"(t.im));  // opaque: keeps cmul(t, rot) from being hoisted into 14 more live VGPRs
+                const cpx t1 = cmul(t, rot);
+                cpx_t<v2f2> tp;
+                tp.re = v2f2{t.re, t1.re};
+                tp.im = v2f2{t.im, t1.im};
+                v[r] = tmul(xv, tp);
+            }
+        }
+        dft8_t(v);
+    }
+    v2_wave_sync();
+    if (active) {
+        if (LGNS == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                uint4 wr, wi;
+                wr.x = v2_pack(v[0].re[u], v[1].re[u]); wr.y = v2_pack(v[2].re[u], v[3].re[u]);
+                wr.z = v2_pack(v[4].re[u], v[5].re[u]); wr.w = v2_pack(v[6].re[u], v[7].re[u]);
+                wi.x = v2_pack(v[0].im[u], v[1].im[u]); wi.y = v2_pack(v[2].im[u], v[3].im[u]);
+                wi.z = v2_pack(v[4].im[u], v[5].im[u]); wi.w = v2_pack(v[6].im[u], v[7].im[u]);
+                *reinterpret_cast<uint4*>(re + v2_off(8 * (2 * t32 + u))) = wr;  // elements 8 j .. 8 j + 7
+                *reinterpret_cast<uint4*>(im + v2_off(8 * (2 * t32 + u))) = wi;
+            }
+        } else {
+            const int j = 2 * t32;
+            const int j0 = ((j >> LGNS) << (LGNS + 3)) | (j & (NS - 1));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                *reinterpret_cast<unsigned*>(re + v2_off(j0 + r * NS)) = v2_pack(v[r].re[0], v[r].re[1]);
+                *reinterpret_cast<unsigned*>(im + v2_off(j0 + r * NS)) = v2_pack(v[r].im[0], v[r].im[1]);
+            }
+        }
+    }
+    v2_wave_sync();
+}
+
+__global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                           const uint4* __restrict__ wfrag, const float* __restrict__ wextra,
+                                                           const float* __restrict__ wtw, int N) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f32[];
+    unsigned char* lds = reinterpret_cast<unsigned char*>(lds_f32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t base = (size_t)blockIdx.x * N * V2D;
+    const int NF = (N + 1) >> 1, JR = 2 * NF, nh1 = N / 2 + 1;
+
+    V2_STAMP(0);
+    // ---- A: x -> LDS (bf16), pad row of an odd N zeroed
+    for (int c = tid; c < N * 64; c += 512) {
+        const int row = c >> 6, ch = c & 63;
+        *reinterpret_cast<uint4*>(lds + row * V2RS + v2_off(ch * 8)) = *reinterpret_cast<const uint4*>(x + base + (size_t)row * V2D + ch * 8);
+    }
+    if (N & 1)
+        for (int c = tid; c < 64; c += 512) *reinterpret_cast<uint4*>(lds + N * V2RS + v2_off(c * 8)) = make_uint4(0, 0, 0, 0);
+    // per-thread twiddles of passes 1 (Ns = 8) and 2 (Ns = 64) for its two butterflies j = 2 t32 + u:
+    // exp(-2 pi i r (j mod Ns) / (8 Ns)), r = 1..7
+    const int t32 = tid & 31, slot = tid >> 5;
+    cpx tw1[7], tw2[7];  // for j = 2 t32 (precomputed table); the odd butterfly's are derived in the pass
+    {
+        const float4* tp = reinterpret_cast<const float4*>(wtw + t32 * 28);
+#pragma unroll
+        for (int q4 = 0; q4 < 7; ++q4) {
+            const float4 tv = tp[q4];  // (re, im) of two consecutive twiddles
+            if (q4 * 2 < 7) tw1[q4 * 2] = cmk(tv.x, tv.y); else tw2[q4 * 2 - 7] = cmk(tv.x, tv.y);
+            if (q4 * 2 + 1 < 7) tw1[q4 * 2 + 1] = cmk(tv.z, tv.w); else tw2[q4 * 2 + 1 - 7] = cmk(tv.z, tv.w);
+        }
+    }
+    __syncthreads();
+    V2_STAMP(1);
+
+    // ---- B: row-pair FFTs, 16 per round
+    for (int f0 = 0; f0 < NF; f0 += 16) {
+        const int f = f0 + slot;
+        const bool active = f < NF;
+        unsigned char* re = lds + (size_t)(2 * (active ? f : 0)) * V2RS;
+        unsigned char* im = re + V2RS;
+        v2_pass<0>(re, im, t32, tw1, active);
+        v2_pass<3>(re, im, t32, tw1, active);
+        v2_pass<6>(re, im, t32, tw2, active);
+    }
+    V2_STAMP(2);
+    __syncthreads();  // all FFT rows are final before any wave reads them as MFMA operands
+    V2_STAMP(3);
+
+    // ---- C: Y1 = W1 . Z, Y2 = W2 . Z for m < 32 on the MFMA pipe; this wave owns columns [64 wave, 64 wave + 64)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.0f;
+    {
+        using lds_ptr = v2s16x4 __attribute__((address_space(3)))*;
+        const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+        const int colb = v2_off(wave * 64 + 16 * (g & 1) + 4 * pp);  // byte offset of this lane's 4 columns inside a row
+#pragma unroll
+        for (int ks = 0; ks < V2KS; ++ks) {
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, wfrag[(0 * V2KS + ks) * 64 + lane]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, wfrag[(1 * V2KS + ks) * 64 + lane]);
+            const int j_lo = min(16 * ks + 8 * (g >> 1) + q, JR - 1);      // rows past JR carry zero weights: clamp
+            const int j_hi = min(16 * ks + 8 * (g >> 1) + q + 4, JR - 1);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const v2s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + j_lo * V2RS + colb + cb * 64));
+                const v2s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + j_hi * V2RS + colb + cb * 64));
+                const v2s16x8 bv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const bf16x8 bfr = __builtin_bit_cast(bf16x8, bv);
+                acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr, acc[cb][0], 0, 0, 0);
+                acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bfr, acc[cb][1], 0, 0, 0);
+            }
+        }
+    }
+    V2_STAMP(4);
+    // row m = 32 (the only one past the MFMA block for tokens <= 65) on the VALU: fp32 weights through the scalar cache
+    // (compile-time offsets -> batched s_load), 80 independent LDS reads in flight; thread tid owns column k = tid
+    float ex0 = 0.0f, ex1 = 0.0f;
+    if (nh1 > 32) {
+#pragma unroll 16
+        for (int j = 0; j < 16 * V2KS; ++j) {
+            const float z = v2_ld(reinterpret_cast<const bf16_t*>(lds + min(j, JR - 1) * V2RS + v2_off(tid)));  // weights are 0 past JR
+            ex0 = fmaf(wextra[j], z, ex0);
+            ex1 = fmaf(wextra[16 * V2KS + j], z, ex1);
+        }
+    }
+    V2_STAMP(5);
+    __syncthreads();  // every read of Z is done: its LDS becomes the Y stage (Y1 rows [0,nh1), Y2 rows [nh1, 2 nh1))
+    V2_STAMP(6);
+
+    {
+        const int h = lane >> 5;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < nh1)
+                        reinterpret_cast<bf16_t*>(lds + (t * nh1 + m) * V2RS)[wave * 64 + cb * 32 + (lane & 31)] = f2bf(acc[cb][t][r]);
+                }
+        if (nh1 > 32) {
+            reinterpret_cast<bf16_t*>(lds + (0 * nh1 + 32) * V2RS)[tid] = f2bf(ex0);
+            reinterpret_cast<bf16_t*>(lds + (1 * nh1 + 32) * V2RS)[tid] = f2bf(ex1);
+        }
+    }
+    V2_STAMP(7);
+    __syncthreads();
+    V2_STAMP(8);
+
+    // ---- D: combine mirrored halves, 8 consecutive frequencies per lane, 16-byte stores
+    for (int c = tid; c < N * 64; c += 512) {
+        const int r = c >> 6, k0 = (c & 63) * 8;
+        const bool low = 2 * r <= N;           // r <= N / 2
+        const int m = low ? r : N - r;
+        const bf16_t* fwd = reinterpret_cast<const bf16_t*>(lds + ((low ? 0 : 1) * nh1 + m) * V2RS);  // read at k
+        const bf16_t* mir = reinterpret_cast<const bf16_t*>(lds + ((low ? 1 : 0) * nh1 + m) * V2RS);  // read at D - k
+        const uint4 fv = *reinterpret_cast<const uint4*>(fwd + k0);
+        const unsigned fw[4] = {fv.x, fv.y, fv.z, fv.w};
+        unsigned o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float a0 = __uint_as_float(fw[u] << 16) + v2_ld(mir + ((V2D - (k0 + 2 * u)) & (V2D - 1)));
+            const float a1 = __uint_as_float(fw[u] & 0xffff0000u) + v2_ld(mir + ((V2D - (k0 + 2 * u + 1)) & (V2D - 1)));
+            o[u] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
+        }
+        *reinterpret_cast<uint4*>(y + base + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    V2_STAMP(9);
+}
+
 // ---------------- generic fallback (any tokens, dim): two direct-DFT kernels through an fp32 workspace
 // stage 1: ws[row][k] = (A, B) = (sum_d x cos(2 pi k d/D), sum_d x sin(..)), one workgroup per row
 __global__ __launch_bounds__(256) void fnet_generic_stage1(const void* __restrict__ x, float2* __restrict__ ws, int D, int bf) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds_f32[];
+    float* lds = lds_f32;
     float* xr = lds;
     float* ct = lds + D;
     float* st = ct + D;
@@ -187,7 +465,8 @@ __global__ __launch_bounds__(256) void fnet_generic_stage1(const void* __restric
 }
 // stage 2: y[b][m][k] = sum_n cos(2 pi m n/N) A[n][k] - sin(..) B[n][k]; grid = (ceil(D/256), B)
 __global__ __launch_bounds__(256) void fnet_generic_stage2(const float2* __restrict__ ws, void* __restrict__ y, int N, int D, int bf) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds_f32[];
+    float* lds = lds_f32;
     float* ct = lds;
     float* st = lds + N;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
@@ -216,7 +495,8 @@ __global__ __launch_bounds__(256) void fnet_generic_stage2(const float2* __restr
 
 // rfft(x).real and its adjoint; one workgroup per row
 __global__ __launch_bounds__(256) void rfft_real_kernel(const void* __restrict__ x, void* __restrict__ y, int D, int transpose, int bf) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds_f32[];
+    float* lds = lds_f32;
     const int K = D / 2 + 1;
     const int n_in = transpose ? K : D, n_out = transpose ? D : K;
     float* xr = lds;
@@ -274,13 +554,21 @@ __global__ __launch_bounds__(256) void haar_level_kernel(const void* __restrict_
 
 }  // namespace
 
-extern "C" int64_t spv_fnet_twiddle_floats(int tokens) { return (int64_t)(tokens + 1) * 2 * FNET_TWS; }
+// table buffer: [v1 token twiddles: (tokens+1)*2*FNET_TWS floats][v2 MFMA weight fragments: 2*5*64*8 bf16][v2 fp32 rows m >= 32]
+static int64_t v2_frag_off(int tokens) { return (int64_t)(tokens + 1) * 2 * FNET_TWS; }
+static int64_t v2_extra_off(int tokens) { return v2_frag_off(tokens) + 2 * V2KS * 64 * 8 / 2; }
+static int64_t v2_tw_off(int tokens) { return v2_extra_off(tokens) + V2XR * 2 * 16 * V2KS; }
+extern "C" int64_t spv_fnet_twiddle_floats(int tokens) { return v2_tw_off(tokens) + 32 * 28; }
 
 extern "C" int spv_fnet_make_twiddle(float* tw, int tokens, void* stream) {
     SPV_CHECK(tokens > 0, "spv_fnet_make_twiddle: tokens=%d", tokens);
     hipLaunchKernelGGL(fnet_twiddle_kernel, dim3(cdiv((tokens + 1) * 2 * FNET_TWS, 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), tw, tokens);
     SPV_LAUNCH_CHECK("spv_fnet_make_twiddle");
+    hipLaunchKernelGGL(fnet_v2_table_kernel, dim3(32), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<bf16_t*>(tw + v2_frag_off(tokens)), tw + v2_extra_off(tokens), tw + v2_tw_off(tokens),
+                       tokens);
+    SPV_LAUNCH_CHECK("spv_fnet_make_twiddle(v2)");
     return 0;
 }
 
@@ -302,6 +590,18 @@ extern "C" int spv_fnet_mix(const void* x, void* y, const float* twiddle, int ba
     SPV_CHECK(dtype == SPV_F32 || dtype == SPV_BF16, "spv_fnet_mix: bad dtype %d", dtype);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int bf = dtype == SPV_BF16;
+    static const bool no_v2 = getenv("SPV_FNET_NO_V2") != nullptr;  // tuning / A-B aid
+    if (bf && dim == V2D && tokens >= 2 && tokens <= 65 && !no_v2) {
+        SPV_CHECK(twiddle != nullptr, "spv_fnet_mix: twiddle table required");
+        const int rows = std::max(2 * ((tokens + 1) / 2), 2 * (tokens / 2 + 1));
+        const size_t lds = (size_t)rows * V2RS;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(fnet_mfma_kernel, dim3(batch), dim3(512), lds, st, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y),
+                           reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)), twiddle + v2_extra_off(tokens),
+                           twiddle + v2_tw_off(tokens), tokens);
+        SPV_LAUNCH_CHECK("spv_fnet_mix(v2)");
+        return 0;
+    }
     if (fnet_fast_ok(tokens, dim)) {
         SPV_CHECK(twiddle != nullptr, "spv_fnet_mix: twiddle table required");
         const size_t lds = ((size_t)(tokens + 1) * dim + 2 * (size_t)dim) * 4;

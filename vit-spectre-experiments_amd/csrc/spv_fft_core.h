@@ -55,6 +55,35 @@ SPV_HD void dft8(cpx* v) {
     for (int q = 0; q < 4; ++q) { v[2 * q] = a[q]; v[2 * q + 1] = b[q]; }
 }
 
+// The same radix-8 butterfly on a generic element type T (float, or a 2-wide vector that lowers to packed
+// v_pk_*_f32 math: two independent butterflies per instruction).
+template <typename T> struct cpx_t { T re, im; };
+template <typename T> SPV_HD cpx_t<T> tadd(cpx_t<T> a, cpx_t<T> b) { cpx_t<T> c; c.re = a.re + b.re; c.im = a.im + b.im; return c; }
+template <typename T> SPV_HD cpx_t<T> tsub(cpx_t<T> a, cpx_t<T> b) { cpx_t<T> c; c.re = a.re - b.re; c.im = a.im - b.im; return c; }
+template <typename T> SPV_HD cpx_t<T> tmul(cpx_t<T> a, cpx_t<T> b) {
+    cpx_t<T> c; c.re = a.re * b.re - a.im * b.im; c.im = a.re * b.im + a.im * b.re; return c;
+}
+template <typename T> SPV_HD cpx_t<T> tmul_mi(cpx_t<T> a) { cpx_t<T> c; c.re = a.im; c.im = -a.re; return c; }
+template <typename T> SPV_HD void dft4_t(cpx_t<T>* v) {
+    cpx_t<T> s02 = tadd(v[0], v[2]), d02 = tsub(v[0], v[2]);
+    cpx_t<T> s13 = tadd(v[1], v[3]), d13 = tmul_mi(tsub(v[1], v[3]));
+    v[0] = tadd(s02, s13);
+    v[1] = tadd(d02, d13);
+    v[2] = tsub(s02, s13);
+    v[3] = tsub(d02, d13);
+}
+template <typename T> SPV_HD void dft8_t(cpx_t<T>* v) {
+    const float h = 0.70710678118654752440f;
+    cpx_t<T> a[4], b[4];
+    for (int n = 0; n < 4; ++n) { a[n] = tadd(v[n], v[n + 4]); b[n] = tsub(v[n], v[n + 4]); }
+    { cpx_t<T> t = b[1]; b[1].re = (t.re + t.im) * h; b[1].im = (t.im - t.re) * h; }   // * (1 - i)/sqrt2
+    b[2] = tmul_mi(b[2]);                                                            // * (-i)
+    { cpx_t<T> t = b[3]; b[3].re = (t.im - t.re) * h; b[3].im = -(t.re + t.im) * h; }  // * (-1 - i)/sqrt2
+    dft4_t(a);
+    dft4_t(b);
+    for (int q = 0; q < 4; ++q) { v[2 * q] = a[q]; v[2 * q + 1] = b[q]; }
+}
+
 // One Stockham butterfly of radix R (2, 4 or 8), sub-transform length Ns, on the planar (re, im) rows of
 // length D.  j in [0, D/R).  tw_re/tw_im: table of exp(-2 pi i t / D), t in [0, D).
 template <int R>
@@ -102,6 +131,16 @@ SPV_HD void unpack_pair(float zr_k, float zr_mk, float zi_k, float zi_mk, float&
     b1 = -0.5f * (zi_k - zi_mk);
     a2 = 0.5f * (zi_k + zi_mk);
     b2 = 0.5f * (zr_k - zr_mk);
+}
+
+// v2 (MFMA) formulation: with Z the planar FFT rows (row 2f = Re, row 2f+1 = Im of FFT(x[2f] + i x[2f+1])),
+//   y[m,k] = sum_j W1[m,j] Z[j][k] + W2[m,j] Z[j][D-k]; for the pair (n1, n2) = (2f, 2f+1) with c = cos, s = sin of
+//   2 pi m n / N (zero for n >= N):
+SPV_HD void fnet_v2_weights(float c1, float s1, float c2, float s2, float& w1_re, float& w1_im, float& w2_re, float& w2_im) {
+    w1_re = 0.5f * (c1 - s2);  // multiplies Zr[k]
+    w1_im = 0.5f * (c2 + s1);  // multiplies Zi[k]
+    w2_re = 0.5f * (c1 + s2);  // multiplies Zr[D-k]
+    w2_im = 0.5f * (c2 - s1);  // multiplies Zi[D-k]
 }
 
 // stage-2 twiddle table layout: tw[n][2][TWS], n in [0, N] (row N all zero: the pad row of an odd N),
