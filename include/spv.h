@@ -159,6 +159,18 @@ int spv_spectral_fold_bwd(const float* dw_full, const float* proj_w, const float
                           int patch, void* stream);
 int spv_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
 
+/* ---- softmax attention core for the baseline ViT ------------------------------------------------
+ * nn.MultiheadAttention inside the stock nn.TransformerEncoderLayer, spectre_vit/models/vit/vit.py:30-38:
+ * ctx = dropout(softmax(Q K^T / sqrt(head_dim))) V per (sequence, head).
+ * qkv [seqs, len, 3*heads*head_dim] (q|k|v), ctx/dctx [seqs, len, heads*head_dim], probs and dscores
+ * [seqs, heads, len, len] (probs is saved for the backward, dscores is scratch of the same size).
+ * len <= 1024, head_dim <= 128.  Which tensor axis is `len` is the caller's business: the reference feeds (B,N,E) with
+ * batch_first=False, so len = B. */
+int spv_attention_fwd(const void* qkv, void* ctx, void* probs, int seqs, int len, int heads, int head_dim, int dtype,
+                      float p_drop, uint64_t seed, void* stream);
+int spv_attention_bwd(const void* dctx, const void* qkv, const void* probs, void* dscores, void* dqkv, int seqs, int len,
+                      int heads, int head_dim, int dtype, float p_drop, uint64_t seed, void* stream);
+
 /* ---- generic helpers used by the module mirror ------------------------------------------------------
  * GELU (TransformerEncoderLayer MLP, vit.py:30-36), column sums (bias / position-embedding gradients;
  * partials: >= min(rows,512)*n floats), a*x + b*y. */

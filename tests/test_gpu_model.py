@@ -176,3 +176,87 @@ def test_state_dict_roundtrip_and_deepcopy():
         assert torch.equal(m(img), m2(img))
     for k, v in m.state_dict().items():
         assert tuple(v.shape) == tuple(sd[k].shape) and str(v.dtype).split(".")[-1] == str(sd[k].dtype), k
+
+
+# ------------------------------------------------------------------------------------------------ baseline ViT
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("seqs,length,heads,hd", [(5, 7, 4, 4), (3, 130, 2, 32), (2, 512, 16, 32), (4, 65, 4, 16)])
+def test_attention_core_vs_oracle(dtype, seqs, length, heads, hd):
+    from spectre_vit import hip_ops
+    rng = np.random.default_rng(seqs * 100 + length)
+    E = heads * hd
+    qkv = n64(t(rng.standard_normal((seqs, length, 3 * E)), dtype))
+    dctx = n64(t(rng.standard_normal((seqs, length, E)), dtype))
+    q, k, v = np.split(qkv, 3, axis=-1)
+    H = lambda a: a.reshape(seqs, length, heads, hd).transpose(0, 2, 1, 3)
+    qh, kh, vh = H(q), H(k), H(v)
+    s = qh @ kh.transpose(0, 1, 3, 2) / np.sqrt(hd)
+    p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    ctx = (p @ vh).transpose(0, 2, 1, 3).reshape(seqs, length, E)
+    dc = H(dctx)
+    dv = p.transpose(0, 1, 3, 2) @ dc
+    dp = dc @ vh.transpose(0, 1, 3, 2)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) / np.sqrt(hd)
+    U = lambda a: a.transpose(0, 2, 1, 3).reshape(seqs, length, E)
+    dqkv = np.concatenate([U(ds @ kh), U(ds.transpose(0, 1, 3, 2) @ qh), U(dv)], axis=-1)
+    X = t(qkv, dtype).requires_grad_(True)
+    Y = hip_ops.AttentionFn.apply(X, heads, 0.0)
+    Y.backward(t(dctx, dtype))
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    check(Y, ctx, tol, "ctx")
+    check(X.grad, dqkv, tol * 2, "dqkv")
+
+
+def test_vit_golden_forward_and_layer_backward(golden_ops):
+    """the reference's own ViT forward (batch-axis attention quirk) and TransformerEncoderLayer backward, fp32"""
+    from spectre_vit.models.vit.vit import ViT, _encoder_layer_forward
+    g = golden_ops
+    m = ViT(img_size=8, patch_size=4, in_channels=3, num_classes=8, embed_dim=16, num_encoders=2, num_heads=4, hidden_dim=24,
+            dropout=0.0).to(dev()).eval()
+    sd = {k[len("vit.sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("vit.sd.")}
+    head_w, head_b = sd.pop("mlp_head.0.weight"), sd.pop("mlp_head.0.bias")  # golden head has 7 classes (not a multiple of 4)
+    m.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        _, cls = m(t(g["vit.x"]), return_features=True)
+    check(cls, g["vit.cls"], 5e-5, "cls")
+    logits = n64(cls) @ head_w.numpy().astype(np.float64).T + head_b.numpy()
+    assert np.abs(logits - g["vit.logits"]).max() < 1e-4
+    assert (cls - cls[0]).abs().max().item() < 1e-5  # SURVEY 0.4: identical for every image under the reference semantics
+    # stock TransformerEncoderLayer forward/backward (batch_first=False: seq axis = dim 0)
+    layer = torch.nn.TransformerEncoderLayer(d_model=16, nhead=4, dim_feedforward=24, dropout=0.0, activation="gelu").to(dev())
+    layer.load_state_dict({k[len("tel.sd."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("tel.sd.")})
+    x = t(g["tel.x"]).requires_grad_(True)
+    y = _encoder_layer_forward(layer, x.transpose(0, 1).contiguous(), False).transpose(0, 1)
+    y.backward(t(g["tel.dy"]))
+    check(y, g["tel.y"], 5e-5, "tel.y")
+    check(x.grad, g["tel.dx"], 2e-4, "tel.dx")
+    for k, p in layer.named_parameters():
+        check(p.grad, g["tel.grad." + k], 3e-4, "tel.grad." + k)
+
+
+def test_vit_state_dict_keys_match_reference(golden_ops):
+    from spectre_vit.models.vit.vit import ViT
+    m = ViT(img_size=8, patch_size=4, in_channels=3, num_classes=7, embed_dim=16, num_encoders=2, num_heads=4, hidden_dim=24, dropout=0.0)
+    ref = {k[len("vit.sd."):]: v for k, v in golden_ops.items() if k.startswith("vit.sd.")}
+    assert list(m.state_dict().keys()) == list(ref.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(ref[k].shape), k
+
+
+@pytest.mark.parametrize("batch_first", [False, True])
+def test_vit_small_bf16_train_step(batch_first):
+    """Small/CIFAR ViT (vit_cifar100 config) bs 64, bf16 autocast: finite loss and gradients; under the reference semantics
+    the logits do not depend on the image, under batch_first=True they do."""
+    from spectre_vit.models.vit.vit import ViT
+    torch.manual_seed(0)
+    m = ViT(img_size=32, patch_size=4, in_channels=3, num_classes=104, embed_dim=512, num_encoders=2, num_heads=16, hidden_dim=768,
+            dropout=0.0, batch_first=batch_first).to(dev())  # dropout 0: masks differ per image and would blur the check below
+    x = torch.randn(64, 3, 32, 32, device=dev())
+    y = torch.randint(0, 100, (64,), device=dev())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = m(x)
+    loss = torch.nn.functional.cross_entropy(out, y)
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters())
+    spread = (out - out[0]).abs().max().item()
+    assert (spread > 1e-3) == batch_first

@@ -1,0 +1,89 @@
+"""Config parser / distillation-loss checks on CPU; the training harness itself on the GPU (f-1, f-2 of SURVEY 8f)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import spectre_oracle as O
+
+
+def test_parse_config_semantics():
+    """reference configs/parser.py:5-27: base overrides child, `_base_` typo dropped, SimpleNamespace result"""
+    from spectre_vit.configs.parser import parse_config
+    c = parse_config("spectre_vit/configs/spectre_vit_cifar100.py")
+    assert (c.img_size, c.patch_size, c.embed_dim, c.num_heads, c.hidden_dim, c.num_encoders) == (32, 4, 512, 16, 768, 4)
+    assert (c.num_classes, c.dropout, c.adam_weight_decay, c.adam_betas, c.num_patches) == (100, 0.001, 0.01, (0.9, 0.999), 64)
+    assert c.random_seed == 42 and c.learning_rate == 1e-3 and c.__base__ == "default.py"
+    m = parse_config("spectre_vit/configs/spectre_vit_mnist.py")
+    assert (m.img_size, m.embed_dim, m.num_heads, m.hidden_dim) == (28, 48, 8, 256)
+    assert not hasattr(m, "random_seed") and not hasattr(m, "_base_")
+
+
+def test_distillation_loss_matches_oracle():
+    from spectre_vit.distillation import distillation_loss
+    g = torch.Generator().manual_seed(3)
+    s = torch.randn(6, 10, generator=g, dtype=torch.float64, requires_grad=True)
+    t = torch.randn(6, 10, generator=g, dtype=torch.float64)
+    y = torch.randint(0, 10, (6,), generator=g)
+    loss, soft, ce = distillation_loss(s, t, y)
+    loss.backward()
+    ref, dref, soft_ref, ce_ref = O.distill_loss_fwd_bwd(s.detach().numpy(), t.numpy(), y.numpy())
+    np.testing.assert_allclose(loss.item(), ref, rtol=1e-12)
+    np.testing.assert_allclose(soft.item(), soft_ref, rtol=1e-12)
+    np.testing.assert_allclose(ce.item(), ce_ref, rtol=1e-12)
+    np.testing.assert_allclose(s.grad.numpy(), dref, rtol=1e-10, atol=1e-14)
+
+
+def test_synthetic_teacher_contract():
+    from spectre_vit.distillation import SyntheticTeacher
+    t = SyntheticTeacher(100, 384, 3)
+    logits, feats = t(torch.randn(4, 3, 64, 64), return_features=True)
+    assert logits.shape == (4, 100) and feats.shape == (4, 384) and not logits.requires_grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("distill", [False, True])
+def test_harness_trains_and_checkpoints(tmp_path, distill):
+    from spectre_vit.harness import train
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    from spectre_vit.configs.parser import parse_config
+    cfg = "spectre_vit/configs/spectre_vit_mnist.py"
+    model, hist = train(cfg, mixer="permut", epochs=3, steps_per_epoch=12, batch_size=64, n_train=1024, n_val=256,
+                        distill=distill, out_dir=str(tmp_path), log=lambda r: None)
+    assert len(hist) == 3 and all(np.isfinite(h["Loss/Train"]) for h in hist)
+    assert hist[-1]["Loss/Train"] < hist[0]["Loss/Train"], hist
+    ck = torch.load(os.path.join(tmp_path, "model_best.pt"), weights_only=True)
+    c = parse_config(cfg)
+    m2 = SpectreViT(img_size=c.img_size, patch_size=c.patch_size, in_channels=c.in_channels, num_classes=c.num_classes,
+                    embed_dim=c.embed_dim, num_encoders=c.num_encoders, num_heads=c.num_heads, hidden_dim=c.hidden_dim,
+                    dropout=c.dropout)
+    m2.load_state_dict(ck, strict=True)  # export.py:59 loads with strict=True
+    assert os.path.exists(os.path.join(tmp_path, "scalars.jsonl"))
+
+
+@pytest.mark.gpu
+def test_first_steps_loss_curve_vs_oracle():
+    """the first optimisation steps on a fixed synthetic batch follow the oracle's loss curve (fp32)."""
+    from conftest import load_model_fixture
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    d, cfg = load_model_fixture("model_small_cut")
+    sd = {k[3:]: v for k, v in d.items() if k.startswith("sd.")}
+    dev = torch.device("cuda:0")
+    m = SpectreViT(**cfg).to(dev)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    img, labels = torch.from_numpy(d["img"]).to(dev), torch.from_numpy(d["labels"]).to(dev)
+    sd64 = {k: np.asarray(v, np.float64) if v.dtype.kind == "f" else v for k, v in sd.items()}
+    state = {}
+    for step in range(1, 5):
+        loss = torch.nn.functional.cross_entropy(m(img), labels)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        ref_loss, _, _, grads = O.train_step(d["img"], d["labels"], sd64, cfg["num_encoders"], cfg["patch_size"], "permut", np.float64)
+        for k, g in grads.items():
+            mv = state.setdefault(k, [np.zeros_like(g), np.zeros_like(g)])
+            sd64[k], mv[0], mv[1] = O.adamw_step(sd64[k], g, mv[0], mv[1], step)
+        assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss), (step, loss.item(), ref_loss)

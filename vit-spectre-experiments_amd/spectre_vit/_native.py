@@ -47,6 +47,8 @@ SIGNATURES = {
     "spv_spectral_fold": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "spv_spectral_fold_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "spv_dropout": [c_vp, c_vp, c_i64, c_f, c_u64, c_i, c_vp],
+    "spv_attention_fwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],
+    "spv_attention_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],
     "spv_gelu_fwd": [c_vp, c_vp, c_i64, c_i, c_vp],
     "spv_gelu_bwd": [c_vp, c_vp, c_vp, c_i64, c_i, c_vp],
     "spv_colsum": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],

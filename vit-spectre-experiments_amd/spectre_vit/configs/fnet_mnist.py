@@ -1,0 +1,4 @@
+"""Config module 'fnet_mnist' (values: configs/_presets.py, which cites the reference file)."""
+from spectre_vit.configs._presets import PRESETS as _P
+
+globals().update(_P["fnet_mnist"])

@@ -1,0 +1,4 @@
+"""Config module 'spectre_branch' (values: configs/_presets.py, which cites the reference file)."""
+from spectre_vit.configs._presets import PRESETS as _P
+
+globals().update(_P["spectre_branch"])

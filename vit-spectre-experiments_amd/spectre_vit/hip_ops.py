@@ -583,3 +583,104 @@ class AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, g
+
+
+# ------------------------------------------------------------------------------------------------
+# baseline ViT pieces: plain Linear, GELU, softmax attention core  (reference vit.py:30-40)
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the MFMA GEMM (nn.Linear: in_proj / out_proj / linear1 / linear2 / the ViT head)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_fp32):
+        _require_gpu(x, weight)
+        n, k = weight.shape
+        x2 = x.reshape(-1, k)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        rows = x2.shape[0]
+        mult = 8 if x2.dtype == torch.bfloat16 else 4
+        if n % mult or k % mult:
+            raise ValueError(f"Linear({k}->{n}) in {x2.dtype}: feature counts must be multiples of {mult}")
+        wc, wt = _shadows.get(weight, x2.dtype)
+        y = torch.empty((rows, n), dtype=torch.float32 if out_fp32 else x2.dtype, device=x2.device)
+        _gemm(x2, wc, bias, y, rows, n, k, k, k, n)
+        ctx.save_for_backward(x2, weight)
+        ctx.wt = wt
+        ctx.meta = (x.shape, rows, n, k, bias is not None)
+        return y.reshape(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        shape, rows, n, k, has_bias = ctx.meta
+        dy2 = dy.reshape(rows, n)
+        if dy2.dtype != x2.dtype:
+            dy2 = _raw_cast(dy2, x2.dtype)
+        elif not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            _gemm(dy2, ctx.wt, None, dx, rows, k, n, n, ctx.wt.shape[1], k)
+            dx = dx.reshape(shape)
+        dw = _weight_grad(dy2, x2, rows, n, k)
+        db = None
+        if has_bias:
+            db = torch.empty((n,), dtype=torch.float32, device=x2.device)
+            part = torch.empty((min(rows, 512) * n,), dtype=torch.float32, device=x2.device)
+            _native.call("spv_colsum", _p(dy2), _p(db), _p(part), rows, n, _dt(dy2), _stream())
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, out_fp32=False):
+    return LinearFn.apply(x, weight, bias, out_fp32)
+
+
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        _native.call("spv_gelu_fwd", _p(xc), _p(y), xc.numel(), _dt(xc), _stream())
+        ctx.save_for_backward(xc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xc,) = ctx.saved_tensors
+        dyc = dy.contiguous()
+        dx = torch.empty_like(xc)
+        _native.call("spv_gelu_bwd", _p(dyc), _p(xc), _p(dx), xc.numel(), _dt(xc), _stream())
+        return dx
+
+
+class AttentionFn(torch.autograd.Function):
+    """ctx = dropout(softmax(q k^T / sqrt(hd))) v per (sequence, head); qkv [seqs, len, 3E] -> [seqs, len, E]."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, p_drop):
+        _require_gpu(qkv)
+        seqs, length, e3 = qkv.shape
+        E = e3 // 3
+        hd = E // heads
+        q = qkv.contiguous()
+        out = torch.empty((seqs, length, E), dtype=q.dtype, device=q.device)
+        probs = torch.empty((seqs, heads, length, length), dtype=q.dtype, device=q.device)
+        seed = _new_seed() if p_drop > 0.0 else 0
+        _native.call("spv_attention_fwd", _p(q), _p(out), _p(probs), seqs, length, heads, hd, _dt(q), float(p_drop), seed, _stream())
+        ctx.save_for_backward(q, probs)
+        ctx.meta = (seqs, length, heads, hd, float(p_drop), seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, probs = ctx.saved_tensors
+        seqs, length, heads, hd, p_drop, seed = ctx.meta
+        d = dout.contiguous()
+        dqkv = torch.empty_like(q)
+        ds = torch.empty_like(probs)
+        _native.call("spv_attention_bwd", _p(d), _p(q), _p(probs), _p(ds), _p(dqkv), seqs, length, heads, hd, _dt(q), p_drop, seed,
+                     _stream())
+        return dqkv, None, None
