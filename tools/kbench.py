@@ -56,6 +56,9 @@ def main():
     tail(768, 512, 0.001)
     tail(512, 768, 0.001)
     tail(768, 512, 0.0)
+    tail(768, 768, 0.0)
+    tail(512, 512, 0.0)
+    tail(768, 1536, 0.0)
     tail(512, 8192, 0.0) if "mix" in "".join(flt) else None
 
     a = torch.randn(ROWS, E, device=dev).to(bf)

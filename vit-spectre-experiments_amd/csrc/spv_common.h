@@ -63,15 +63,28 @@ template <> struct io<bf16_t> {
 };
 
 // ---------------------------------------------------------------- wave64 reductions
+// DPP (data-parallel primitives) inside each 16-lane row, then the four row totals through v_readlane: ~12 cheap VALU
+// ops.  (__shfl_xor lowers to ds_bpermute_b32 -- six serialised LDS round trips per reduction, which left the
+// one-wave-per-row kernels waiting most of the time.)  Every lane gets the result.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_lane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x128>(v);   // row_ror:8  -> each lane holds the sum of its 16-lane row
+    return (row_lane(v, 0) + row_lane(v, 16)) + (row_lane(v, 32) + row_lane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    return fmaxf(fmaxf(row_lane(v, 0), row_lane(v, 16)), fmaxf(row_lane(v, 32), row_lane(v, 48)));
 }
 
 // ---------------------------------------------------------------- math
@@ -104,6 +117,8 @@ __device__ __forceinline__ unsigned dropout_row_key(uint64_t seed, uint64_t row)
     return mix32((unsigned)seed + (unsigned)row * 0x9e3779b1u) ^ mix32((unsigned)(seed >> 32) + (unsigned)(row >> 32));
 }
 __device__ __forceinline__ float dropout_scale(unsigned row_key, unsigned col, float p, float inv_keep) {
-    const unsigned h = mix32(row_key + col * 0x9e3779b1u);
-    return (float)(h >> 8) * (1.0f / 16777216.0f) < p ? 0.0f : inv_keep;
+    // one finaliser per PAIR of columns, 16 bits each (drop probability quantised to 1/65536)
+    const unsigned h = mix32(row_key + (col >> 1) * 0x9e3779b1u);
+    const unsigned u16 = (col & 1) ? (h >> 16) : (h & 0xffffu);
+    return u16 < (unsigned)(p * 65536.0f + 0.5f) ? 0.0f : inv_keep;
 }

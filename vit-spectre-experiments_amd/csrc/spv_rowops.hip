@@ -102,26 +102,27 @@ __device__ __forceinline__ void write_partials(float (&acc)[NP][MAXI][VEC], floa
 
 // ------------------------------------------------------------------------------------------------
 template <int VEC, int MAXI>
-__global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h, const void* __restrict__ x,
+__global__ __launch_bounds__(RT, 4) void tail_fwd_kernel(const void* __restrict__ h, const void* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        void* __restrict__ out, float* __restrict__ mean_o,
                                                        float* __restrict__ rstd_o, int rows, int n, int k_in, int bf,
                                                        int out_bf, float p_drop, uint64_t seed, int pool_mode) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    int* win_s = reinterpret_cast<int*>(lds);  // POOL_TABLE: window start / end per output channel
-    int* win_e = win_s + n;
+    const int pw = k_in / n;  // POOL_EXACT window
+    const float inv_pw = 1.0f / (float)(pw > 0 ? pw : 1);
+    const int lane = threadIdx.x & 63;
+    // POOL_TABLE: per output channel, window start | count << 16 and 1 / count (LDS tables: register copies cost occupancy)
+    int* win_s = reinterpret_cast<int*>(lds);
+    float* win_inv = lds + n;
     if (pool_mode == POOL_TABLE) {
         for (int c = threadIdx.x; c < n; c += RT) {
             int s, e;
             pool_window(c, k_in, n, s, e);
-            win_s[c] = s;
-            win_e[c] = e;
+            win_s[c] = s | ((e - s) << 16);
+            win_inv[c] = 1.0f / (float)(e - s);
         }
         __syncthreads();
     }
-    const int pw = k_in / n;  // POOL_EXACT window
-    const float inv_pw = 1.0f / (float)(pw > 0 ? pw : 1);
-    const int lane = threadIdx.x & 63;
     float* xs = lds + 2 * n + (threadIdx.x >> 6) * k_in;  // POOL_TABLE: this wave's fp32 copy of the input row
     const bool exact4 = pool_mode == POOL_EXACT && (pw & 3) == 0 && VEC == 4;
     float* xq = lds + (threadIdx.x >> 6) * (k_in >> 2);   // POOL_EXACT (pw % 4 == 0): per-wave sums of 4 inputs
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h
         }
         float mean, rstd;
         row_stats<VEC, MAXI>(hv, n, lane, mean, rstd);
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
         if (exact4) {
             // coalesced pass over the input row: lane sums 4 consecutive inputs; the owner of an output adds pw/4 of them
             lds_fence();
@@ -190,10 +192,13 @@ __global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h
             } else {
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    const int s = win_s[e0 + k], e = win_e[e0 + k];
-                    float acc = 0.0f;
-                    for (int j = s; j < e; ++j) acc += xs[j];
-                    pv[k] = acc / (float)(e - s);
+                    const int sc = win_s[e0 + k];
+                    const int s = sc & 0xffff, cnt = sc >> 16;
+                    float acc = xs[s];
+                    if (cnt > 1) acc += xs[s + 1];
+                    if (cnt > 2) acc += xs[s + 2];
+                    for (int j = 3; j < cnt; ++j) acc += xs[s + j];
+                    pv[k] = acc * win_inv[e0 + k];
                 }
             }
 #pragma unroll
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h
                 if (bf) gelu_fast(ln, act, dact_unused);
                 else act = gelu_erf(ln);
                 o[k] = act + pv[k];
-                if (p_drop > 0.0f) o[k] *= dropout_scale(seed, (uint64_t)row * n + e0 + k, p_drop, inv_keep);
+                if (p_drop > 0.0f) o[k] *= dropout_scale(rkey, (unsigned)(e0 + k), p_drop, inv_keep);
             }
             stv<VEC>(out, (size_t)row * n + e0, out_bf, o);
         }
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(RT) void tail_fwd_kernel(const void* __restrict__ h
 }
 
 template <int VEC, int MAXI>
-__global__ __launch_bounds__(RT) void tail_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ h,
+__global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ h,
                                                        const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        void* __restrict__ dh, void* __restrict__ dxp,
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(RT) void tail_bwd_kernel(const void* __restrict__ d
 
     for (int row = wave_g; row < rows; row += nwaves) {
         const float mean = mean_i[row], rstd = rstd_i[row];
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
         float xh[MAXI][VEC], dxh[MAXI][VEC];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(RT) void tail_bwd_kernel(const void* __restrict__ d
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
                     float d = dv[k];
-                    if (p_drop > 0.0f) d *= dropout_scale(seed, (uint64_t)row * n + e0 + k, p_drop, inv_keep);
+                    if (p_drop > 0.0f) d *= dropout_scale(rkey, (unsigned)(e0 + k), p_drop, inv_keep);
                     dv[k] = d;
                     float xhat = (hv[k] - mean) * rstd;
                     float dgel, act_unused;
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(RT) void tail_bwd_kernel(const void* __restrict__ d
                 for (int j0 = lane * 4; j0 < k_in; j0 += 256) {
                     const int c = j0 / pw;
                     float d = ld1(dout, (size_t)row * n + c, dout_bf);
-                    if (p_drop > 0.0f) d *= dropout_scale(seed, (uint64_t)row * n + c, p_drop, inv_keep);
+                    if (p_drop > 0.0f) d *= dropout_scale(rkey, (unsigned)c, p_drop, inv_keep);
                     d *= inv_pw;
                     float o[VEC];
 #pragma unroll
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(RT) void tail_bwd_kernel(const void* __restrict__ d
                 for (int j = lane; j < k_in; j += 64) {
                     const int c = j / pw;
                     float d = ld1(dout, (size_t)row * n + c, dout_bf);
-                    if (p_drop > 0.0f) d *= dropout_scale(seed, (uint64_t)row * n + c, p_drop, inv_keep);
+                    if (p_drop > 0.0f) d *= dropout_scale(rkey, (unsigned)c, p_drop, inv_keep);
                     st1(dxp, (size_t)row * k_in + j, bf, d * inv_pw);
                 }
             }

@@ -4,9 +4,11 @@ The reference is single-process (spectre_vit/repl/train.py:41); the step shards 
 op mixes samples, so the only exchange is one gradient all-reduce per step.  One process per GPU,
 ``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm); gloo on CPU for the tests.
 
-GradReducer keeps every parameter's ``.grad`` as a view into a few large flat fp32 buckets laid out in reverse
-registration order (~ the order backward produces them: head -> last layer -> ... -> embedding).  A
-post-accumulate hook counts a bucket's parameters; when the bucket is complete its all-reduce is launched
+GradReducer lays a few large flat fp32 buckets out in reverse registration order (~ the order backward produces the
+gradients: head -> last layer -> ... -> embedding) and hands every parameter its slot as a ``GradSink``: the HIP backward
+kernels write dW / db / dgamma ... directly into the bucket, autograd adopts that view as ``p.grad`` (no extra
+``grad += new`` pass).  A post-accumulate hook (which also stages gradients that arrived from other ops) counts a
+bucket's parameters; when the bucket is complete its all-reduce is launched
 asynchronously on RCCL's own stream while backward continues, and ``finish()`` waits for all of them before the
 optimizer runs.  xGMI is point-to-point (7 links x ~153 GB/s), so few large buckets are used rather than many
 small ones; ``reduce_dtype=torch.bfloat16`` halves the bytes on the links (sum still accumulated by RCCL in bf16,
@@ -26,8 +28,12 @@ class GradReducer:
         self.reduce_dtype = reduce_dtype
         self.buckets = []  # dict(flat, params, pending, handle, stage)
         self._bucket_of = {}
-        if not self.params:
-            return
+        if not self.params or self.world == 1:
+            return  # single process: no exchange, gradients stay ordinary per-parameter tensors
+        try:
+            from spectre_vit.hip_ops import GradSink
+        except Exception:  # the reducer itself is model agnostic (CPU gloo tests use a stock model)
+            GradSink = None
         cap = int(bucket_mb * 1024 * 1024 / 4)
         cur, cur_n = [], 0
         groups = []
@@ -43,20 +49,27 @@ class GradReducer:
             n = sum(p.numel() for p in ps)
             flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
             off = 0
+            views = []
             for p in ps:
-                p.grad = flat[off:off + p.numel()].view_as(p)
+                v = flat[off:off + p.numel()].view_as(p)
+                views.append(v)
+                if GradSink is not None and p.is_cuda:
+                    p._spv_grad_sink = GradSink(v)  # backward kernels write the gradient straight into the bucket
                 off += p.numel()
                 self._bucket_of[p] = bi
-            self.buckets.append(dict(flat=flat, params=ps, pending=len(ps), handle=None, stage=None))
-        if self.world > 1:
-            for p in self.params:
-                p.register_post_accumulate_grad_hook(self._hook)
+            self.buckets.append(dict(flat=flat, params=ps, views=views, pending=len(ps), handle=None, stage=None))
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
 
     # -- per step ---------------------------------------------------------------------------------
     def zero_grad(self):
-        """replaces optimizer.zero_grad(): gradients live in the flat buckets (keep set_to_none=False semantics)."""
+        """replaces optimizer.zero_grad(set_to_none=True); re-arms the buckets."""
+        for p in self.params:
+            p.grad = None
+            s = getattr(p, "_spv_grad_sink", None)
+            if s is not None:
+                s.used = False
         for b in self.buckets:
-            b["flat"].zero_()
             b["pending"] = len(b["params"])
             b["handle"] = None
 
@@ -69,6 +82,11 @@ class GradReducer:
 
     def _hook(self, p):
         b = self.buckets[self._bucket_of[p]]
+        idx = b.setdefault("index", {id(q): i for i, q in enumerate(b["params"])})[id(p)]
+        v = b["views"][idx]
+        if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)  # gradient came from an op that did not write into the bucket: stage it
+        p.grad = v
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
@@ -79,7 +97,10 @@ class GradReducer:
             return
         inv = 1.0 / self.world
         for b in self.buckets:
-            if b["handle"] is None:  # a parameter of this bucket received no gradient this step
+            if b["handle"] is None:  # a parameter of this bucket received no gradient this step: its slot is stale -> zero
+                for q, v in zip(b["params"], b["views"]):
+                    if q.grad is None:
+                        v.zero_()
                 self._launch(b)
             b["handle"].wait()
             if b["stage"] is not None:

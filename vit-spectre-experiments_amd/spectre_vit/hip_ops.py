@@ -200,11 +200,11 @@ def _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, 
                  _p(workspace), _stream())
 
 
-def _weight_grad(dh, x, rows, n, k):
+def _weight_grad(dh, x, rows, n, k, sink=None):
     """dW[n,k] = dh[rows,n]^T . x[rows,k], split-K over rows.  bf16: TN kernel straight from the row-major activations
     (transposing LDS reads); fp32 (parity path): NT kernel over explicit transposes."""
     dev = dh.device
-    dw = torch.empty((n, k), dtype=torch.float32, device=dev)
+    dw = _grad_buf(sink, (n, k), dev)
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
     splits = max(1, min(1024 // tiles, (rows + 511) // 512))
     ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev) if splits > 1 else None
@@ -224,6 +224,30 @@ def _weight_grad(dh, x, rows, n, k):
     _native.call("spv_cast_transpose", _p(x), _dt(x), _p(xt), _dt(xt), rows, k, ld, 0, 0, 0, st)
     _gemm(dht, xt, None, dw, n, k, ld, ld, ld, k, 0, splits, ws)
     return dw
+
+
+class GradSink:
+    """A parameter's slot in a flat gradient bucket (installed by spectre_vit.dp.GradReducer as ``p._spv_grad_sink``).
+    Backward kernels write a parameter's gradient straight into the slot, so autograd's AccumulateGrad adopts that
+    tensor as ``p.grad`` without the extra ``grad += new`` pass over every weight.  ``used`` guards the (never taken
+    here) case of a parameter that receives two gradient contributions in one step: the second one goes to fresh memory
+    and autograd sums them."""
+    __slots__ = ("view", "used")
+
+    def __init__(self, view):
+        self.view = view
+        self.used = False
+
+
+def _sink(p):
+    return getattr(p, "_spv_grad_sink", None)
+
+
+def _grad_buf(sink, shape, device):
+    if sink is not None and not sink.used and tuple(sink.view.shape) == tuple(shape):
+        sink.used = True
+        return sink.view
+    return torch.empty(shape, dtype=torch.float32, device=device)
 
 
 def _new_seed():
@@ -259,6 +283,7 @@ class SpectreLinearFn(torch.autograd.Function):
                      _dt(h), _dt(out), float(p_drop), seed, _stream())
         ctx.save_for_backward(x2, h, mean, rstd, weight, gamma, beta)
         ctx.wt = wt
+        ctx.sinks = (_sink(weight), _sink(bias), _sink(gamma), _sink(beta))
         ctx.meta = (shape, rows, n, k, float(p_drop), seed)
         return out.reshape(*shape[:-1], n)
 
@@ -273,9 +298,10 @@ class SpectreLinearFn(torch.autograd.Function):
             dout2 = dout2.contiguous()
         dh = torch.empty_like(h)
         dx = torch.empty_like(x2)
-        dgamma = torch.empty((n,), dtype=torch.float32, device=dev)
-        dbeta = torch.empty_like(dgamma)
-        dbias = torch.empty_like(dgamma)
+        s_w, s_b, s_g, s_be = ctx.sinks
+        dgamma = _grad_buf(s_g, (n,), dev)
+        dbeta = _grad_buf(s_be, (n,), dev)
+        dbias = _grad_buf(s_b, (n,), dev)
         partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=dev)
         _native.call("spv_spectre_tail_bwd", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
                      _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed, _stream())
@@ -286,7 +312,7 @@ class SpectreLinearFn(torch.autograd.Function):
             dx_out = dx.reshape(shape)
         else:
             dx_out = None
-        dw = _weight_grad(dh, x2, rows, n, k)
+        dw = _weight_grad(dh, x2, rows, n, k, s_w)
         return dx_out, dw, dbias, dgamma, dbeta, None, None
 
 
@@ -311,6 +337,7 @@ class AddLayerNormFn(torch.autograd.Function):
         _native.call("spv_add_layernorm_fwd", _p(a2), _p(b2), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, n, mode,
                      _dt(a2), _stream())
         ctx.save_for_backward(a2, b2, mean, rstd, gamma)
+        ctx.sinks = (_sink(gamma), _sink(beta))
         ctx.meta = (a.shape, rows, n, mode)
         return out.reshape(a.shape)
 
@@ -320,8 +347,8 @@ class AddLayerNormFn(torch.autograd.Function):
         shape, rows, n, mode = ctx.meta
         d2 = dout.reshape(rows, n).contiguous()
         din = torch.empty_like(a2)
-        dgamma = torch.empty((n,), dtype=torch.float32, device=a2.device)
-        dbeta = torch.empty_like(dgamma)
+        dgamma = _grad_buf(ctx.sinks[0], (n,), a2.device)
+        dbeta = _grad_buf(ctx.sinks[1], (n,), a2.device)
         partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=a2.device)
         _native.call("spv_add_layernorm_bwd", _p(d2), _p(a2), _p(b2), _p(mean), _p(rstd), _p(gamma), _p(din), _p(dgamma),
                      _p(dbeta), _p(partials), rows, n, mode, _dt(a2), _stream())
@@ -470,6 +497,7 @@ class SpectralFoldFn(torch.autograd.Function):
         wf = torch.empty((E, chans * patch * patch), dtype=torch.float32, device=proj_w.device)
         _native.call("spv_spectral_fold", _p(proj_w), _p(fh), _p(fw), _p(wf), E, chans, patch, _stream())
         ctx.save_for_backward(proj_w, fh, fw)
+        ctx.sinks = (_sink(proj_w), _sink(fh), _sink(fw))
         ctx.meta = (E, chans, patch)
         return wf
 
@@ -478,9 +506,9 @@ class SpectralFoldFn(torch.autograd.Function):
         proj_w, fh, fw = ctx.saved_tensors
         E, chans, patch = ctx.meta
         dwf = dwf.contiguous()
-        dw = torch.empty_like(proj_w)
-        dfh = torch.empty_like(fh)
-        dfw = torch.empty_like(fw)
+        dw = _grad_buf(ctx.sinks[0], proj_w.shape, proj_w.device)
+        dfh = _grad_buf(ctx.sinks[1], fh.shape, fh.device)
+        dfw = _grad_buf(ctx.sinks[2], fw.shape, fw.device)
         scratch = torch.empty_like(proj_w)
         _native.call("spv_spectral_fold_bwd", _p(dwf), _p(proj_w), _p(fh), _p(fw), _p(dw), _p(dfh), _p(dfw), _p(scratch), E,
                      chans, patch, _stream())
@@ -607,6 +635,7 @@ class LinearFn(torch.autograd.Function):
         _gemm(x2, wc, bias, y, rows, n, k, k, k, n)
         ctx.save_for_backward(x2, weight)
         ctx.wt = wt
+        ctx.sinks = (_sink(weight), _sink(bias))
         ctx.meta = (x.shape, rows, n, k, bias is not None)
         return y.reshape(*x.shape[:-1], n)
 
@@ -624,10 +653,10 @@ class LinearFn(torch.autograd.Function):
             dx = torch.empty_like(x2)
             _gemm(dy2, ctx.wt, None, dx, rows, k, n, n, ctx.wt.shape[1], k)
             dx = dx.reshape(shape)
-        dw = _weight_grad(dy2, x2, rows, n, k)
+        dw = _weight_grad(dy2, x2, rows, n, k, ctx.sinks[0])
         db = None
         if has_bias:
-            db = torch.empty((n,), dtype=torch.float32, device=x2.device)
+            db = _grad_buf(ctx.sinks[1], (n,), x2.device)
             part = torch.empty((min(rows, 512) * n,), dtype=torch.float32, device=x2.device)
             _native.call("spv_colsum", _p(dy2), _p(db), _p(part), rows, n, _dt(dy2), _stream())
         return dx, dw, db, None
