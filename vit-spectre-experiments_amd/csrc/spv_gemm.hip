@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
                                                       const float* __restrict__ bias, TO* __restrict__ C,
                                                       float* __restrict__ ws, int M, int N, int K, int lda,
                                                       int ldb, int ldc, int k_per_split, int accumulate,
-                                                      int tiles_n, int tiles_mn, int rg, int gs, int roff,
+                                                      int tiles_n, int tiles_mn, int nsplit, int rg, int gs, int roff,
                                                       const float* __restrict__ bias2d) {
     constexpr int BK = KT<T>::BK;
     constexpr int CH = KT<T>::CH;
@@ -156,8 +156,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int split = blockIdx.y;
-    const int tile = xcd_remap(blockIdx.x, tiles_mn);
+    // one linear id over (split, tile), XCD-remapped as a whole: each XCD gets whole K-slices, so the tiles that
+    // share a slice's operand rows hit in that XCD's L2 (per-slice round-robin made every XCD fetch every slice:
+    // 3.4x the algorithmic HBM reads on the weight-gradient GEMM, FETCH_SIZE)
+    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);
+    const int split = lin / tiles_mn;
+    const int tile = lin % tiles_mn;
     // consecutive tile ids sweep the N tiles of one M panel -> the A panel is fetched once per XCD
     const int tm = tile / tiles_n, tn = tile % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
                                                            const float* __restrict__ bias, TO* __restrict__ C,
                                                            float* __restrict__ ws, int M, int N, int K, int lda, int ldb,
                                                            int ldc, int k_per_split, int accumulate, int tiles_n,
-                                                           int tiles_mn, int rg, int gs, int roff,
+                                                           int tiles_mn, int nsplit, int rg, int gs, int roff,
                                                            const float* __restrict__ bias2d) {
     constexpr int CPR = KB / 16;              // 16-byte chunks per tile row
     constexpr int RPI = 64 / CPR;             // tile rows written by one wave instruction (1 KiB)
@@ -280,8 +284,12 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int split = blockIdx.y;
-    const int tile = xcd_remap(blockIdx.x, tiles_mn);
+    // one linear id over (split, tile), XCD-remapped as a whole: each XCD gets whole K-slices, so the tiles that
+    // share a slice's operand rows hit in that XCD's L2 (per-slice round-robin made every XCD fetch every slice:
+    // 3.4x the algorithmic HBM reads on the weight-gradient GEMM, FETCH_SIZE)
+    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);
+    const int split = lin / tiles_mn;
+    const int tile = lin % tiles_mn;
     const int tm = tile / tiles_n, tn = tile % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = split * k_per_split;
@@ -373,14 +381,18 @@ template <typename TO>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                       TO* __restrict__ C, float* __restrict__ ws, int M, int N, int K, int lda,
                                                       int ldb, int ldc, int k_per_split, int accumulate, int tiles_n,
-                                                      int tiles_mn) {
+                                                      int tiles_mn, int nsplit) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * ROWB];  // 36 864 B >= 2 * TBK * TROWB = 20 480 B
     unsigned char* sA = smem;
     unsigned char* sB = smem + TBK * TROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int split = blockIdx.y;
-    const int tile = xcd_remap(blockIdx.x, tiles_mn);
+    // one linear id over (split, tile), XCD-remapped as a whole: each XCD gets whole K-slices, so the tiles that
+    // share a slice's operand rows hit in that XCD's L2 (per-slice round-robin made every XCD fetch every slice:
+    // 3.4x the algorithmic HBM reads on the weight-gradient GEMM, FETCH_SIZE)
+    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);
+    const int split = lin / tiles_mn;
+    const int tile = lin % tiles_mn;
     const int tm = tile / tiles_n, tn = tile % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = split * k_per_split;
@@ -476,7 +488,7 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
         splits = cdiv(K, k_per_split);
     }
     float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
-    dim3 grid(tiles_m * tiles_n, splits);
+    dim3 grid(tiles_m * tiles_n * splits);
     if constexpr (sizeof(T) == 2) {
         // direct-to-LDS double-buffered kernel for long reductions (measured: 896 vs 795 TFLOP/s at 4096^3, 755 vs 700 on
         // the 512 x 8192 x 33280 weight gradient); the skinny K <= 1024 layer GEMMs are faster on the register-staged
@@ -487,18 +499,18 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
             if (kb == 64)
                 hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 64>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                    static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                                   accumulate, tiles_n, tiles_m * tiles_n, rg, gs, roff, bias2d);
+                                   accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d);
             else
                 hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 128>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                    static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                                   accumulate, tiles_n, tiles_m * tiles_n, rg, gs, roff, bias2d);
+                                   accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d);
             SPV_LAUNCH_CHECK("spv_gemm_nt(glds)");
             goto reduce;
         }
     }
     hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), grid, dim3(256), 0, st, static_cast<const T*>(A),
                        static_cast<const T*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                       accumulate, tiles_n, tiles_m * tiles_n, rg, gs, roff, bias2d);
+                       accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d);
     SPV_LAUNCH_CHECK("spv_gemm_nt");
 reduce:
     if (splits > 1) {
@@ -572,13 +584,13 @@ extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, 
         splits = cdiv(K, k_per_split);
     }
     float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
-    dim3 grid(tiles_m * tiles_n, splits);
+    dim3 grid(tiles_m * tiles_n * splits);
     if (out_dtype == SPV_BF16)
         hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, ws, M, N,
-                           K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n);
+                           K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n, splits);
     else
         hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (float*)C, ws, M, N, K,
-                           lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n);
+                           lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n, splits);
     SPV_LAUNCH_CHECK("spv_gemm_tn");
     if (splits > 1) {
         int blocks = (int)std::min<int64_t>(((int64_t)M * N + 255) / 256, 2048);

@@ -101,7 +101,7 @@ __device__ __forceinline__ void write_partials(float (&acc)[NP][MAXI][VEC], floa
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int VEC, int MAXI>
+template <int VEC, int MAXI, bool FASTG>
 __global__ __launch_bounds__(RT, 4) void tail_fwd_kernel(const void* __restrict__ h, const void* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        void* __restrict__ out, float* __restrict__ mean_o,
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_kernel(const void* __restrict_
             for (int k = 0; k < VEC; ++k) {
                 float ln = (hv[i][k] - mean) * rstd * g[k] + b[k];
                 float act, dact_unused;
-                if (bf) gelu_fast(ln, act, dact_unused);
+                if (FASTG) gelu_fast(ln, act, dact_unused);
                 else act = gelu_erf(ln);
                 o[k] = act + pv[k];
                 if (p_drop > 0.0f) o[k] *= dropout_scale(rkey, (unsigned)(e0 + k), p_drop, inv_keep);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_kernel(const void* __restrict_
     }
 }
 
-template <int VEC, int MAXI>
+template <int VEC, int MAXI, bool FASTG>
 __global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ h,
                                                        const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict_
                     dv[k] = d;
                     float xhat = (hv[k] - mean) * rstd;
                     float dgel, act_unused;
-                    if (bf) gelu_fast(xhat * g[k] + b[k], act_unused, dgel);
+                    if (FASTG) gelu_fast(xhat * g[k] + b[k], act_unused, dgel);
                     else dgel = gelu_erf_grad(xhat * g[k] + b[k]);
                     float dln = d * dgel;
                     acc[0][i][k] += dln * xhat;
@@ -491,6 +491,25 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
     }
 }
 
+#define TAIL_DISPATCH(cfg, fast, KERNEL, grid, lds_bytes, st, ...)                                              \
+    do {                                                                                                       \
+        if (fast) {                                                                                            \
+            if (cfg.vec == 4 && cfg.maxi == 2) hipLaunchKernelGGL((KERNEL<4, 2, true>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);        \
+            else if (cfg.vec == 4 && cfg.maxi == 3) hipLaunchKernelGGL((KERNEL<4, 3, true>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);   \
+            else if (cfg.vec == 4 && cfg.maxi == 4) hipLaunchKernelGGL((KERNEL<4, 4, true>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);   \
+            else if (cfg.vec == 4 && cfg.maxi == 12) hipLaunchKernelGGL((KERNEL<4, 12, true>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__); \
+            else if (cfg.vec == 4 && cfg.maxi == 16) hipLaunchKernelGGL((KERNEL<4, 16, true>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<1, 16, true>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);         \
+        } else {                                                                                               \
+            if (cfg.vec == 4 && cfg.maxi == 2) hipLaunchKernelGGL((KERNEL<4, 2, false>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);        \
+            else if (cfg.vec == 4 && cfg.maxi == 3) hipLaunchKernelGGL((KERNEL<4, 3, false>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);   \
+            else if (cfg.vec == 4 && cfg.maxi == 4) hipLaunchKernelGGL((KERNEL<4, 4, false>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);   \
+            else if (cfg.vec == 4 && cfg.maxi == 12) hipLaunchKernelGGL((KERNEL<4, 12, false>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__); \
+            else if (cfg.vec == 4 && cfg.maxi == 16) hipLaunchKernelGGL((KERNEL<4, 16, false>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__); \
+            else hipLaunchKernelGGL((KERNEL<1, 16, false>), grid, dim3(RT), lds_bytes, st, __VA_ARGS__);        \
+        }                                                                                                      \
+    } while (0)
+
 struct RowCfg { int vec, maxi; };
 inline bool pick_cfg(int n, RowCfg& c) {
     if (n % 4 == 0) {
@@ -536,7 +555,7 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
     const size_t lds_f = pm == POOL_TABLE ? ((size_t)2 * n + (size_t)RW * k_in) * sizeof(float)
                          : (pm == POOL_EXACT && (k_in / n) % 4 == 0 ? (size_t)RW * (k_in / 4) * sizeof(float) : 0);
     SPV_CHECK(lds_f <= 64 * 1024, "spv_spectre_tail_fwd: n=%d k_in=%d needs %zu bytes of LDS", n, k_in, lds_f);
-    ROW_DISPATCH(cfg, tail_fwd_kernel, grid, lds_f, st, h, x, gamma, beta, out, mean,
+    TAIL_DISPATCH(cfg, dtype == SPV_BF16, tail_fwd_kernel, grid, lds_f, st, h, x, gamma, beta, out, mean,
                  rstd, rows, n, k_in, dtype == SPV_BF16, out_dtype == SPV_BF16, p_drop, seed, pm);
     SPV_LAUNCH_CHECK("spv_spectre_tail_fwd");
     return 0;
@@ -556,7 +575,7 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
     const int wgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
     const size_t lds = (size_t)3 * n * sizeof(float) + (pm == POOL_TABLE ? (size_t)(2 * k_in + n + RW * n) * sizeof(int) : 0);
     SPV_CHECK(lds <= 64 * 1024, "spv_spectre_tail_bwd: n=%d k_in=%d needs %zu bytes of LDS", n, k_in, lds);
-    ROW_DISPATCH(cfg, tail_bwd_kernel, dim3(wgs), lds, st, dout, h, mean, rstd, gamma, beta, dh,
+    TAIL_DISPATCH(cfg, dtype == SPV_BF16, tail_bwd_kernel, dim3(wgs), lds, st, dout, h, mean, rstd, gamma, beta, dh,
                  dx_pool, partials, rows, n, k_in, dtype == SPV_BF16, dout_dtype == SPV_BF16, p_drop, seed, pm);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd");
     hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, 32)), dim3(256), 0, st, partials, dgamma, dbeta, dbias, wgs, 3, n);

@@ -10,7 +10,7 @@ kernels write dW / db / dgamma ... directly into the bucket, autograd adopts tha
 ``grad += new`` pass).  A post-accumulate hook (which also stages gradients that arrived from other ops) counts a
 bucket's parameters; when the bucket is complete its all-reduce is launched
 asynchronously on RCCL's own stream while backward continues, and ``finish()`` waits for all of them before the
-optimizer runs.  xGMI is point-to-point (7 links x ~153 GB/s), so few large buckets are used rather than many
+optimizer runs.  xGMI is point-to-point (7 links x ~153 GB/s), so a few multi-megabyte buckets are used rather than many
 small ones; ``reduce_dtype=torch.bfloat16`` halves the bytes on the links (sum still accumulated by RCCL in bf16,
 so it is off by default).
 """
@@ -21,11 +21,13 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 32.0, process_group=None, reduce_dtype=None):
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 8.0, process_group=None, reduce_dtype=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.reduce_dtype = reduce_dtype
+        # RCCL averages in the collective itself (ncclAvg); gloo only sums -> scale afterwards
+        self._avg = self.world > 1 and dist.get_backend(process_group) == "nccl" and reduce_dtype in (None, torch.float32)
         self.buckets = []  # dict(flat, params, pending, handle, stage)
         self._bucket_of = {}
         if not self.params or self.world == 1:
@@ -78,7 +80,8 @@ class GradReducer:
             b["stage"] = b["flat"].to(self.reduce_dtype)
             b["handle"] = dist.all_reduce(b["stage"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
-            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group,
+                                          async_op=True)
 
     def _hook(self, p):
         b = self.buckets[self._bucket_of[p]]
@@ -106,7 +109,8 @@ class GradReducer:
             if b["stage"] is not None:
                 b["flat"].copy_(b["stage"])
                 b["stage"] = None
-            b["flat"].mul_(inv)
+            if not self._avg:
+                b["flat"].mul_(inv)
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0, process_group=None):
