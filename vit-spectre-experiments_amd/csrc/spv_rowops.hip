@@ -491,6 +491,162 @@ __global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lane-contiguous variants of the SpectreLinear tail for channel counts that are multiples of 64 with a small
+// rational pooling ratio (Small: 512 -> 768 and 768 -> 512).  Lane t owns outputs [t*CO, (t+1)*CO) and, because the
+// adaptive windows [floor(c*k/n), ceil((c+1)*k/n)) never cross a multiple of k/64, exactly the inputs
+// [t*CI, (t+1)*CI): the avg-pool skip and its transpose are lane-local with COMPILE-TIME windows -- no LDS stage, no
+// tables, no divergent window loops (the general path spends ~24 us per call on them).
+constexpr int lc_ws(int c, int CO, int CI) { return (c * CI) / CO; }
+constexpr int lc_we(int c, int CO, int CI) { return ((c + 1) * CI + CO - 1) / CO; }
+
+template <int CNT> __device__ __forceinline__ void ld_span(const void* base, size_t off, int bf, float (&v)[CNT]) {
+#pragma unroll
+    for (int q = 0; q < CNT / 4; ++q) {
+        float t[4];
+        ldv<4>(base, off + 4 * q, bf, t);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[4 * q + u] = t[u];
+    }
+}
+template <int CNT> __device__ __forceinline__ void st_span(void* base, size_t off, int bf, const float (&v)[CNT]) {
+#pragma unroll
+    for (int q = 0; q < CNT / 4; ++q) {
+        float t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = v[4 * q + u];
+        stv<4>(base, off + 4 * q, bf, t);
+    }
+}
+
+template <int CO, int CI, bool FASTG>
+__global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restrict__ h, const void* __restrict__ x,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             void* __restrict__ out, float* __restrict__ mean_o,
+                                                             float* __restrict__ rstd_o, int rows, int bf, int out_bf, float p_drop,
+                                                             uint64_t seed) {
+    constexpr int n = 64 * CO, k_in = 64 * CI;
+    const int lane = threadIdx.x & 63;
+    const int wave_g = blockIdx.x * RW + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * RW;
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    float g[CO], b[CO];
+    ld_span<CO>(gamma, (size_t)lane * CO, 0, g);
+    ld_span<CO>(beta, (size_t)lane * CO, 0, b);
+    for (int row = wave_g; row < rows; row += nwaves) {
+        float hv[CO], xin[CI];
+        ld_span<CO>(h, (size_t)row * n + lane * CO, bf, hv);
+        ld_span<CI>(x, (size_t)row * k_in + lane * CI, bf, xin);
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) s += hv[c];
+        const float mean = wave_sum(s) / (float)n;
+        float q = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) { const float d = hv[c] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / (float)n + LN_EPS);
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
+        float o[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            constexpr int dummy = 0; (void)dummy;
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CI; ++j)
+                if (j >= lc_ws(c, CO, CI) && j < lc_we(c, CO, CI)) acc += xin[j];
+            const float pv = acc * (1.0f / (float)(lc_we(c, CO, CI) - lc_ws(c, CO, CI)));
+            const float ln = (hv[c] - mean) * rstd * g[c] + b[c];
+            float act, unused;
+            if (FASTG) gelu_fast(ln, act, unused);
+            else act = gelu_erf(ln);
+            o[c] = act + pv;
+            if (p_drop > 0.0f) o[c] *= dropout_scale(rkey, (unsigned)(lane * CO + c), p_drop, inv_keep);
+        }
+        st_span<CO>(out, (size_t)row * n + lane * CO, out_bf, o);
+        if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+    }
+}
+
+template <int CO, int CI, bool FASTG>
+__global__ __launch_bounds__(RT, (CO > 8 ? 3 : 4)) void tail_bwd_lc_kernel(const void* __restrict__ dout, const void* __restrict__ h,
+                                                             const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             void* __restrict__ dh, void* __restrict__ dxp, float* __restrict__ partials,
+                                                             int rows, int bf, int dout_bf, float p_drop, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int n = 64 * CO, k_in = 64 * CI;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_g = blockIdx.x * RW + wave;
+    const int nwaves = gridDim.x * RW;
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    float acc[3][CO];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[p][c] = 0.0f;
+    for (int row = wave_g; row < rows; row += nwaves) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
+        // register diet (this kernel is occupancy bound): gamma/beta are re-read per row (L1 hits) and xhat is recomputed
+        // from h in the second pass instead of being kept
+        float hv[CO], dv[CO], dxh[CO], g[CO], b[CO];
+        ld_span<CO>(h, (size_t)row * n + lane * CO, bf, hv);
+        ld_span<CO>(dout, (size_t)row * n + lane * CO, dout_bf, dv);
+        ld_span<CO>(gamma, (size_t)lane * CO, 0, g);
+        ld_span<CO>(beta, (size_t)lane * CO, 0, b);
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            if (p_drop > 0.0f) dv[c] *= dropout_scale(rkey, (unsigned)(lane * CO + c), p_drop, inv_keep);
+            const float xhat = (hv[c] - mean) * rstd;
+            float dgel, unused;
+            if (FASTG) gelu_fast(xhat * g[c] + b[c], unused, dgel);
+            else dgel = gelu_erf_grad(xhat * g[c] + b[c]);
+            const float dln = dv[c] * dgel;
+            acc[0][c] += dln * xhat;
+            acc[1][c] += dln;
+            const float t = dln * g[c];
+            dxh[c] = t;
+            s1 += t;
+            s2 += t * xhat;
+        }
+        const float m1 = wave_sum(s1) / (float)n, m2 = wave_sum(s2) / (float)n;
+        float o[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            o[c] = rstd * (dxh[c] - m1 - (hv[c] - mean) * rstd * m2);
+            acc[2][c] += o[c];
+        }
+        st_span<CO>(dh, (size_t)row * n + lane * CO, bf, o);
+        // transposed pooling, lane local: input j receives dout[c] / width(c) from every window that covers it
+        float dx[CI];
+#pragma unroll
+        for (int j = 0; j < CI; ++j) {
+            float a = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CO; ++c)
+                if (j >= lc_ws(c, CO, CI) && j < lc_we(c, CO, CI)) a += dv[c] * (1.0f / (float)(lc_we(c, CO, CI) - lc_ws(c, CO, CI)));
+            dx[j] = a;
+        }
+        st_span<CI>(dxp, (size_t)row * k_in + lane * CI, bf, dx);
+    }
+    // fold the 4 waves' column partials through LDS in wave order, one slab per workgroup
+    for (int w = 0; w < RW; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int c = 0; c < CO; ++c) {
+                    float* qd = lds + p * n + lane * CO + c;
+                    *qd = (w == 0 ? 0.0f : *qd) + acc[p][c];
+                }
+        }
+        __syncthreads();
+    }
+    float* slab = partials + (size_t)blockIdx.x * 3 * n;
+    for (int c = threadIdx.x; c < 3 * n; c += blockDim.x) slab[c] = lds[c];
+}
+
 #define TAIL_DISPATCH(cfg, fast, KERNEL, grid, lds_bytes, st, ...)                                              \
     do {                                                                                                       \
         if (fast) {                                                                                            \
@@ -550,6 +706,20 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
     SPV_CHECK(pick_cfg(n, cfg), "spv_spectre_tail_fwd: unsupported row length %d", n);
     hipStream_t st = static_cast<hipStream_t>(stream);
     SPV_CHECK((int64_t)n * k_in < (1ll << 31), "spv_spectre_tail_fwd: n*k_in too large");
+    {
+        const int fast = dtype == SPV_BF16, bfl = dtype == SPV_BF16, obf = out_dtype == SPV_BF16;
+        dim3 lgrid(std::min(cdiv(rows, RW), 2048));
+#define LC_FWD(CO, CI)                                                                                                        \
+        if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
+            if (fast) hipLaunchKernelGGL((tail_fwd_lc_kernel<CO, CI, true>), lgrid, dim3(RT), 0, static_cast<hipStream_t>(stream), h, x, gamma, beta, out, mean, rstd, rows, bfl, obf, p_drop, seed); \
+            else hipLaunchKernelGGL((tail_fwd_lc_kernel<CO, CI, false>), lgrid, dim3(RT), 0, static_cast<hipStream_t>(stream), h, x, gamma, beta, out, mean, rstd, rows, bfl, obf, p_drop, seed);    \
+            SPV_LAUNCH_CHECK("spv_spectre_tail_fwd(lc)");                                                                     \
+            return 0;                                                                                                         \
+        }
+        LC_FWD(12, 8)
+        LC_FWD(8, 12)
+#undef LC_FWD
+    }
     const int pm = pool_mode_of(n, k_in);
     dim3 grid(std::min(cdiv(rows, RW), 2048));
     const size_t lds_f = pm == POOL_TABLE ? ((size_t)2 * n + (size_t)RW * k_in) * sizeof(float)
@@ -571,6 +741,23 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
     SPV_CHECK(pick_cfg(n, cfg), "spv_spectre_tail_bwd: unsupported row length %d", n);
     hipStream_t st = static_cast<hipStream_t>(stream);
     SPV_CHECK((int64_t)n * k_in < (1ll << 31), "spv_spectre_tail_bwd: n*k_in too large");
+    {
+        const int fast = dtype == SPV_BF16, bfl = dtype == SPV_BF16, dbf = dout_dtype == SPV_BF16;
+        const int lwgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
+#define LC_BWD(CO, CI)                                                                                                        \
+        if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
+            hipStream_t lst = static_cast<hipStream_t>(stream);                                                               \
+            if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true>), dim3(lwgs), dim3(RT), (size_t)3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed); \
+            else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false>), dim3(lwgs), dim3(RT), (size_t)3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed);    \
+            SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc)");                                                                     \
+            hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, 32)), dim3(256), 0, lst, partials, dgamma, dbeta, dbias, lwgs, 3, n); \
+            SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc fold)");                                                                \
+            return 0;                                                                                                         \
+        }
+        LC_BWD(12, 8)
+        LC_BWD(8, 12)
+#undef LC_BWD
+    }
     const int pm = pool_mode_of(n, k_in);
     const int wgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
     const size_t lds = (size_t)3 * n * sizeof(float) + (pm == POOL_TABLE ? (size_t)(2 * k_in + n + RW * n) * sizeof(int) : 0);
