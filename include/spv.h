@@ -78,11 +78,12 @@ int spv_spectre_tail_fwd(const void* h, const void* x, const float* gamma, const
 /* Backward of the tail.  dout [rows,n] (dout_dtype) -> dh [rows,n] (dtype), dx_pool [rows,k_in] (dtype; the
  * transposed pooling of the masked dout, to which the caller accumulates dh.W), and the fp32
  * column sums dgamma/dbeta/dbias [n].  `partials` is fp32 scratch of spv_rowop_partial_floats(n)
- * floats. */
+ * floats.  `dx_add` (nullable, [rows,k_in], dtype): a residual-stream gradient folded into dx_pool
+ * (x1 feeds both norm2's residual and linear1, spectre.py:67,70-73), instead of a separate add pass. */
 int spv_spectre_tail_bwd(const void* dout, const void* h, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, void* dh, void* dx_pool, float* dgamma,
                          float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype,
-                         int dout_dtype, float p_drop, uint64_t seed, void* stream);
+                         int dout_dtype, float p_drop, uint64_t seed, const void* dx_add, void* stream);
 int64_t spv_rowop_partial_floats(int n);
 
 /* ---- residual + LayerNorm ------------------------------------------------------------------------
@@ -115,9 +116,10 @@ int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* dx, int bat
  * `twiddle`: token-axis cos/sin table of spv_fnet_twiddle_floats(tokens) floats filled once by
  * spv_fnet_make_twiddle (the caller caches it).  `workspace`: fp32 scratch of
  * spv_fnet_workspace_floats(batch,tokens,dim) floats (0 on the LDS fast path: dim a power of two,
- * tokens <= 79 and (tokens+3)*dim*4 <= 160 KiB). */
-int spv_fnet_mix(const void* x, void* y, const float* twiddle, int batch, int tokens, int dim, int dtype,
-                 float* workspace, void* stream);
+ * tokens <= 79 and (tokens+3)*dim*4 <= 160 KiB).  `add_in` (nullable, same shape/dtype as y) is added to the
+ * output: in the backward, the residual-stream gradient that bypasses the mixer (spectre.py:66). */
+int spv_fnet_mix(const void* x, void* y, const void* add_in, const float* twiddle, int batch, int tokens, int dim,
+                 int dtype, float* workspace, void* stream);
 int64_t spv_fnet_workspace_floats(int batch, int tokens, int dim);
 int64_t spv_fnet_twiddle_floats(int tokens);
 int spv_fnet_make_twiddle(float* twiddle, int tokens, void* stream);

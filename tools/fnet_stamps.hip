@@ -19,7 +19,7 @@ int main() {
     hipMemset(st, 0, (size_t)B * 8 * 16 * 8);
     spv_fnet_make_twiddle(tw, N, nullptr);
     hipMemcpyToSymbol(HIP_SYMBOL(g_fnet_stamps), &st, sizeof(st));
-    for (int it = 0; it < 3; ++it) spv_fnet_mix(x, y, tw, B, N, D, SPV_BF16, nullptr, nullptr);
+    for (int it = 0; it < 3; ++it) spv_fnet_mix(x, y, nullptr, tw, B, N, D, SPV_BF16, nullptr, nullptr);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h((size_t)B * 8 * 16);
     hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);

@@ -47,7 +47,7 @@ def main():
         part = torch.empty(_native.call("spv_rowop_partial_floats", n), device=dev)
         fwd = lambda: _native.call("spv_spectre_tail_fwd", p(h), p(x), p(g), p(be), p(out), p(mean), p(rstd), ROWS, n, k, 1, 1, pd, 7, st)
         bwd = lambda: _native.call("spv_spectre_tail_bwd", p(out), p(h), p(mean), p(rstd), p(g), p(be), p(dh), p(dx), p(dg), p(db),
-                                   p(dbi), p(part), ROWS, n, k, 1, 1, pd, 7, st)
+                                   p(dbi), p(part), ROWS, n, k, 1, 1, pd, 7, 0, st)
         byt_f = ROWS * (2 * n + k) * 2
         byt_b = ROWS * (3 * n + k) * 2
         cases.append((f"tail_fwd n={n} k={k} p={pd}", fwd, byt_f, None))
@@ -105,6 +105,9 @@ def main():
     gemm_tn(F, E, ROWS, 12)
     gemm_tn(E, F, ROWS, 12)
     gemm_tn(F, E, ROWS, 42)
+    gemm_tn(F, E, ROWS, 21)
+    gemm_tn(F, E, ROWS, 28)
+    gemm_tn(F, E, ROWS, 64)
     t1 = torch.empty(F, ROWS, device=dev, dtype=bf)
     hh = torch.randn(ROWS, F, device=dev).to(bf)
     cases.append(("cast_transpose 33280x768 bf16", lambda: _native.call("spv_cast_transpose", p(hh), 1, p(t1), 1, ROWS, F, ROWS, 0, 0, 0, st), ROWS * F * 4, None))

@@ -25,6 +25,11 @@ __device__ __forceinline__ void st1(void* base, size_t off, int bf, float v) {
     if (bf) static_cast<bf16_t*>(base)[off] = f2bf(v);
     else static_cast<float*>(base)[off] = v;
 }
+// store v (+ add_in[off] when a residual is folded into the mixer's output)
+__device__ __forceinline__ void st1a(void* base, const void* add_in, size_t off, int bf, float v) {
+    if (add_in != nullptr) v += ld1(add_in, off, bf);
+    st1(base, off, bf, v);
+}
 
 __global__ __launch_bounds__(256) void fnet_twiddle_kernel(float* __restrict__ tw, int N) {
     const int total = (N + 1) * 2 * FNET_TWS;
@@ -62,7 +67,7 @@ __device__ __forceinline__ void pass_radix(float* re, float* im, const float* tw
 template <int MH>
 __global__ __launch_bounds__(FT) void fnet_lds_kernel(const void* __restrict__ x, void* __restrict__ y,
                                                       const float* __restrict__ tw2, int N, int D, int log2tpf, FftPlan plan,
-                                                      int bf) {
+                                                      int bf, const void* __restrict__ add_in) {
     extern __shared__ __attribute__((aligned(16))) float lds_f32[];
     float* lds = lds_f32;
     float* twr = lds + (size_t)(N + 1) * D;
@@ -137,11 +142,11 @@ __global__ __launch_bounds__(FT) void fnet_lds_kernel(const void* __restrict__ x
                 const int M = m_off + m;
                 const int mm = M == 0 ? 0 : N - M;
                 const float d = P[m] - Q[m], s = P[m] + Q[m];
-                st1(y, base + (size_t)M * D + k, bf, d);
-                if (mm != M) st1(y, base + (size_t)mm * D + k, bf, s);
+                st1a(y, add_in, base + (size_t)M * D + k, bf, d);
+                if (mm != M) st1a(y, add_in, base + (size_t)mm * D + k, bf, s);
                 if (k != 0) {
-                    st1(y, base + (size_t)M * D + mk, bf, s);
-                    if (mm != M) st1(y, base + (size_t)mm * D + mk, bf, d);
+                    st1a(y, add_in, base + (size_t)M * D + mk, bf, s);
+                    if (mm != M) st1a(y, add_in, base + (size_t)mm * D + mk, bf, d);
                 }
             }
         }
@@ -155,8 +160,8 @@ __global__ __launch_bounds__(FT) void fnet_lds_kernel(const void* __restrict__ x
             P += tw2[(size_t)(2 * f) * 2 * FNET_TWS + M] * a1 + tw2[(size_t)(2 * f + 1) * 2 * FNET_TWS + M] * a2;
         }
         const int mm = M == 0 ? 0 : N - M;
-        st1(y, base + (size_t)M * D + Dh, bf, P);
-        if (mm != M) st1(y, base + (size_t)mm * D + Dh, bf, P);
+        st1a(y, add_in, base + (size_t)M * D + Dh, bf, P);
+        if (mm != M) st1a(y, add_in, base + (size_t)mm * D + Dh, bf, P);
     }
 }
 
@@ -302,13 +307,20 @@ __device__ __forceinline__ void v2_pass(unsigned char* re, unsigned char* im, in
 
 __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                            const uint4* __restrict__ wfrag, const float* __restrict__ wextra,
-                                                           const float* __restrict__ wtw, int N) {
+                                                           const float* __restrict__ wtw, int N, int stagger,
+                                                           const bf16_t* __restrict__ add_in) {
     extern __shared__ __attribute__((aligned(16))) float lds_f32[];
     unsigned char* lds = reinterpret_cast<unsigned char*>(lds_f32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t base = (size_t)blockIdx.x * N * V2D;
     const int NF = (N + 1) >> 1, JR = 2 * NF, nh1 = N / 2 + 1;
 
+    // Phase stagger: with batch = 2 x CUs every CU gets exactly two workgroups and, launched together, they would all
+    // load, then all compute, then all store -- HBM idle while the VALUs work and vice versa.  The second half of the
+    // grid (the second workgroup of each CU under in-order dispatch; a performance assumption only) sleeps through the
+    // first half's load phase, so its loads overlap their FFTs and its FFTs overlap their stores.
+    if (stagger > 0 && blockIdx.x >= (gridDim.x >> 1))
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
     V2_STAMP(0);
     // ---- A: x -> LDS (bf16), pad row of an odd N zeroed
     for (int c = tid; c < N * 64; c += 512) {
@@ -422,11 +434,15 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
         const bf16_t* mir = reinterpret_cast<const bf16_t*>(lds + ((low ? 1 : 0) * nh1 + m) * V2RS);  // read at D - k
         const uint4 fv = *reinterpret_cast<const uint4*>(fwd + k0);
         const unsigned fw[4] = {fv.x, fv.y, fv.z, fv.w};
+        uint4 av = make_uint4(0, 0, 0, 0);  // bf16 zeros
+        if (add_in != nullptr) av = *reinterpret_cast<const uint4*>(add_in + base + (size_t)r * V2D + k0);
+        const unsigned aw[4] = {av.x, av.y, av.z, av.w};
         unsigned o[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float a0 = __uint_as_float(fw[u] << 16) + v2_ld(mir + ((V2D - (k0 + 2 * u)) & (V2D - 1)));
-            const float a1 = __uint_as_float(fw[u] & 0xffff0000u) + v2_ld(mir + ((V2D - (k0 + 2 * u + 1)) & (V2D - 1)));
+            const float a0 = __uint_as_float(fw[u] << 16) + v2_ld(mir + ((V2D - (k0 + 2 * u)) & (V2D - 1))) + __uint_as_float(aw[u] << 16);
+            const float a1 = __uint_as_float(fw[u] & 0xffff0000u) + v2_ld(mir + ((V2D - (k0 + 2 * u + 1)) & (V2D - 1))) +
+                             __uint_as_float(aw[u] & 0xffff0000u);
             o[u] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
         }
         *reinterpret_cast<uint4*>(y + base + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
@@ -464,7 +480,8 @@ __global__ __launch_bounds__(256) void fnet_generic_stage1(const void* __restric
     }
 }
 // stage 2: y[b][m][k] = sum_n cos(2 pi m n/N) A[n][k] - sin(..) B[n][k]; grid = (ceil(D/256), B)
-__global__ __launch_bounds__(256) void fnet_generic_stage2(const float2* __restrict__ ws, void* __restrict__ y, int N, int D, int bf) {
+__global__ __launch_bounds__(256) void fnet_generic_stage2(const float2* __restrict__ ws, void* __restrict__ y, int N, int D, int bf,
+                                                           const void* __restrict__ add_in) {
     extern __shared__ __attribute__((aligned(16))) float lds_f32[];
     float* lds = lds_f32;
     float* ct = lds;
@@ -489,7 +506,7 @@ __global__ __launch_bounds__(256) void fnet_generic_stage2(const float2* __restr
             idx += m;
             if (idx >= N) idx -= N;
         }
-        st1(y, base + (size_t)m * D + k, bf, acc);
+        st1a(y, add_in, base + (size_t)m * D + k, bf, acc);
     }
 }
 
@@ -584,8 +601,8 @@ extern "C" int64_t spv_fnet_workspace_floats(int batch, int tokens, int dim) {
     return fnet_fast_ok(tokens, dim) ? 0 : (int64_t)batch * tokens * dim * 2;
 }
 
-extern "C" int spv_fnet_mix(const void* x, void* y, const float* twiddle, int batch, int tokens, int dim, int dtype,
-                            float* workspace, void* stream) {
+extern "C" int spv_fnet_mix(const void* x, void* y, const void* add_in, const float* twiddle, int batch, int tokens, int dim,
+                            int dtype, float* workspace, void* stream) {
     SPV_CHECK(batch > 0 && tokens > 0 && dim > 0, "spv_fnet_mix: empty");
     SPV_CHECK(dtype == SPV_F32 || dtype == SPV_BF16, "spv_fnet_mix: bad dtype %d", dtype);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -593,12 +610,14 @@ extern "C" int spv_fnet_mix(const void* x, void* y, const float* twiddle, int ba
     static const bool no_v2 = getenv("SPV_FNET_NO_V2") != nullptr;  // tuning / A-B aid
     if (bf && dim == V2D && tokens >= 2 && tokens <= 65 && !no_v2) {
         SPV_CHECK(twiddle != nullptr, "spv_fnet_mix: twiddle table required");
+        static const int stagger_env = getenv("SPV_FNET_STAGGER") ? atoi(getenv("SPV_FNET_STAGGER")) : -1;
+        const int v2_stagger = stagger_env >= 0 ? stagger_env : (batch >= 512 ? 1 : 0);  // x 8128 cycles (~3.5 us)
         const int rows = std::max(2 * ((tokens + 1) / 2), 2 * (tokens / 2 + 1));
         const size_t lds = (size_t)rows * V2RS;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(fnet_mfma_kernel, dim3(batch), dim3(512), lds, st, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y),
                            reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)), twiddle + v2_extra_off(tokens),
-                           twiddle + v2_tw_off(tokens), tokens);
+                           twiddle + v2_tw_off(tokens), tokens, v2_stagger, static_cast<const bf16_t*>(add_in));
         SPV_LAUNCH_CHECK("spv_fnet_mix(v2)");
         return 0;
     }
@@ -613,7 +632,7 @@ extern "C" int spv_fnet_mix(const void* x, void* y, const float* twiddle, int ba
         do {                                                                                                               \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_lds_kernel<MHV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 160 * 1024);                                                                               \
-            hipLaunchKernelGGL((fnet_lds_kernel<MHV>), dim3(batch), dim3(FT), lds, st, x, y, twiddle, tokens, dim, log2tpf, plan, bf); \
+            hipLaunchKernelGGL((fnet_lds_kernel<MHV>), dim3(batch), dim3(FT), lds, st, x, y, twiddle, tokens, dim, log2tpf, plan, bf, add_in); \
         } while (0)
         if (mh <= 4) FNET_LAUNCH(4);
         else if (mh <= 9) FNET_LAUNCH(9);
@@ -630,7 +649,7 @@ extern "C" int spv_fnet_mix(const void* x, void* y, const float* twiddle, int ba
                        reinterpret_cast<float2*>(workspace), dim, bf);
     SPV_LAUNCH_CHECK("spv_fnet_mix(stage1)");
     hipLaunchKernelGGL(fnet_generic_stage2, dim3(cdiv(dim, 256), batch), dim3(256), (size_t)tokens * 8, st,
-                       reinterpret_cast<const float2*>(workspace), y, tokens, dim, bf);
+                       reinterpret_cast<const float2*>(workspace), y, tokens, dim, bf, add_in);
     SPV_LAUNCH_CHECK("spv_fnet_mix(stage2)");
     return 0;
 }

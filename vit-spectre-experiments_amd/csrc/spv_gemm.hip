@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
 // 320-byte row stride the four k rows of a group land in four disjoint 16-bank ranges (conflict free).
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 constexpr int TROWB = 256 + 64;  // LDS bytes per k row (128 bf16 + pad)
-constexpr int TBK = 32;          // k rows per stage
+constexpr int TBK = 64;          // k rows per stage (16 MFMAs per wave between barriers)
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
     // base: this lane's address for rows k0..k0+3; the second read covers rows k0+4..k0+7
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
                                                       TO* __restrict__ C, float* __restrict__ ws, int M, int N, int K, int lda,
                                                       int ldb, int ldc, int k_per_split, int accumulate, int tiles_n,
                                                       int tiles_mn, int nsplit) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * ROWB];  // 36 864 B >= 2 * TBK * TROWB = 20 480 B
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TBK * TROWB];  // 40 960 B (>= the epilogue's 36 864 B)
     unsigned char* sA = smem;
     unsigned char* sB = smem + TBK * TROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -398,13 +398,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     const int kbeg = split * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
 
-    // staging map: TBK = 32 k rows x 16 chunks of 16 B per operand = 512 chunks -> 2 per thread per operand
-    const int srow = tid >> 4, sch = tid & 15;  // rows srow, srow + 16
+    // staging map: TBK k rows x 16 chunks of 16 B per operand -> TBK / 16 chunks per thread per operand
+    const int srow = tid >> 4, sch = tid & 15;  // rows srow + 16 i
     const bool a_ok = (m0 + sch * 8) < M, b_ok = (n0 + sch * 8) < N;  // M, N multiples of 8: a chunk is all in or all out
-    uint4 ra[2], rb[2];
+    uint4 ra[TBK / 16], rb[TBK / 16];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TBK / 16; ++i) {
             const int k = k0 + srow + 16 * i;
             const bool kin = k < kend;
             ra[i] = (kin && a_ok) ? *reinterpret_cast<const uint4*>(A + (size_t)k * lda + m0 + sch * 8) : make_uint4(0, 0, 0, 0);
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TBK / 16; ++i) {
             *reinterpret_cast<uint4*>(sA + (srow + 16 * i) * TROWB + sch * 16) = ra[i];
             *reinterpret_cast<uint4*>(sB + (srow + 16 * i) * TROWB + sch * 16) = rb[i];
         }

@@ -222,7 +222,8 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict_
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        void* __restrict__ dh, void* __restrict__ dxp,
                                                        float* __restrict__ partials, int rows, int n, int k_in, int bf,
-                                                       int dout_bf, float p_drop, uint64_t seed, int pool_mode) {
+                                                       int dout_bf, float p_drop, uint64_t seed, int pool_mode,
+                                                       const void* __restrict__ dx_add) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // LDS: [3n] partial fold | POOL_TABLE: c_lo[k_in], c_hi[k_in], inv_w[n]
     int* c_lo_t = reinterpret_cast<int*>(lds + 3 * n);
@@ -288,7 +289,18 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict_
                     s1 += t;
                     s2 += t * xhat;
                 }
-                if (pool_mode == POOL_IDENT) stv<VEC>(dxp, (size_t)row * k_in + e0, bf, dv);  // identity skip
+                if (pool_mode == POOL_IDENT) {  // identity skip
+                    if (dx_add != nullptr) {
+                        float ad[VEC];
+                        ldv<VEC>(dx_add, (size_t)row * k_in + e0, bf, ad);
+                        float t[VEC];
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) t[k] = dv[k] + ad[k];
+                        stv<VEC>(dxp, (size_t)row * k_in + e0, bf, t);
+                    } else {
+                        stv<VEC>(dxp, (size_t)row * k_in + e0, bf, dv);
+                    }
+                }
                 else if (pool_mode == POOL_TABLE) {
 #pragma unroll
                     for (int k = 0; k < VEC; ++k) ds[e0 + k] = dv[k];
@@ -323,6 +335,12 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict_
                     float o[VEC];
 #pragma unroll
                     for (int u = 0; u < VEC; ++u) o[u] = d;
+                    if (dx_add != nullptr) {
+                        float ad[VEC];
+                        ldv<VEC>(dx_add, (size_t)row * k_in + j0, bf, ad);
+#pragma unroll
+                        for (int u = 0; u < VEC; ++u) o[u] += ad[u];
+                    }
                     stv<VEC>(dxp, (size_t)row * k_in + j0, bf, o);
                 }
             } else {
@@ -330,7 +348,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict_
                     const int c = j / pw;
                     float d = ld1(dout, (size_t)row * n + c, dout_bf);
                     if (p_drop > 0.0f) d *= dropout_scale(rkey, (unsigned)c, p_drop, inv_keep);
-                    st1(dxp, (size_t)row * k_in + j, bf, d * inv_pw);
+                    st1(dxp, (size_t)row * k_in + j, bf, d * inv_pw + (dx_add ? ld1(dx_add, (size_t)row * k_in + j, bf) : 0.0f));
                 }
             }
         } else if (pool_mode == POOL_TABLE) {
@@ -339,6 +357,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict_
                 const int c_lo = c_lo_t[j], c_hi = c_hi_t[j];
                 float a = 0.0f;
                 for (int c = c_lo; c <= c_hi; ++c) a += ds[c] * inv_w_t[c];
+                if (dx_add != nullptr) a += ld1(dx_add, (size_t)row * k_in + j, bf);
                 st1(dxp, (size_t)row * k_in + j, bf, a);
             }
             lds_fence();  // pooled reads done before the next row overwrites the stage
@@ -572,7 +591,8 @@ __global__ __launch_bounds__(RT, (CO > 8 ? 3 : 4)) void tail_bwd_lc_kernel(const
                                                              const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              void* __restrict__ dh, void* __restrict__ dxp, float* __restrict__ partials,
-                                                             int rows, int bf, int dout_bf, float p_drop, uint64_t seed) {
+                                                             int rows, int bf, int dout_bf, float p_drop, uint64_t seed,
+                                                             const void* __restrict__ dx_add) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int n = 64 * CO, k_in = 64 * CI;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -627,6 +647,12 @@ __global__ __launch_bounds__(RT, (CO > 8 ? 3 : 4)) void tail_bwd_lc_kernel(const
             for (int c = 0; c < CO; ++c)
                 if (j >= lc_ws(c, CO, CI) && j < lc_we(c, CO, CI)) a += dv[c] * (1.0f / (float)(lc_we(c, CO, CI) - lc_ws(c, CO, CI)));
             dx[j] = a;
+        }
+        if (dx_add != nullptr) {  // residual gradient folded in here instead of a separate elementwise add
+            float ad[CI];
+            ld_span<CI>(dx_add, (size_t)row * k_in + lane * CI, bf, ad);
+#pragma unroll
+            for (int j = 0; j < CI; ++j) dx[j] += ad[j];
         }
         st_span<CI>(dxp, (size_t)row * k_in + lane * CI, bf, dx);
     }
@@ -734,7 +760,7 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
 extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float* mean, const float* rstd,
                                     const float* gamma, const float* beta, void* dh, void* dx_pool, float* dgamma,
                                     float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype,
-                                    int dout_dtype, float p_drop, uint64_t seed, void* stream) {
+                                    int dout_dtype, float p_drop, uint64_t seed, const void* dx_add, void* stream) {
     SPV_CHECK(rows > 0 && n > 0 && k_in > 0, "spv_spectre_tail_bwd: empty");
     SPV_CHECK(check_dtype(dtype) && check_dtype(dout_dtype), "spv_spectre_tail_bwd: bad dtype");
     RowCfg cfg;
@@ -747,8 +773,8 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
 #define LC_BWD(CO, CI)                                                                                                        \
         if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
             hipStream_t lst = static_cast<hipStream_t>(stream);                                                               \
-            if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true>), dim3(lwgs), dim3(RT), (size_t)3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed); \
-            else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false>), dim3(lwgs), dim3(RT), (size_t)3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed);    \
+            if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true>), dim3(lwgs), dim3(RT), (size_t)3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add); \
+            else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false>), dim3(lwgs), dim3(RT), (size_t)3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add);    \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc)");                                                                     \
             hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, 32)), dim3(256), 0, lst, partials, dgamma, dbeta, dbias, lwgs, 3, n); \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc fold)");                                                                \
@@ -763,7 +789,7 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
     const size_t lds = (size_t)3 * n * sizeof(float) + (pm == POOL_TABLE ? (size_t)(2 * k_in + n + RW * n) * sizeof(int) : 0);
     SPV_CHECK(lds <= 64 * 1024, "spv_spectre_tail_bwd: n=%d k_in=%d needs %zu bytes of LDS", n, k_in, lds);
     TAIL_DISPATCH(cfg, dtype == SPV_BF16, tail_bwd_kernel, dim3(wgs), lds, st, dout, h, mean, rstd, gamma, beta, dh,
-                 dx_pool, partials, rows, n, k_in, dtype == SPV_BF16, dout_dtype == SPV_BF16, p_drop, seed, pm);
+                 dx_pool, partials, rows, n, k_in, dtype == SPV_BF16, dout_dtype == SPV_BF16, p_drop, seed, pm, dx_add);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd");
     hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, 32)), dim3(256), 0, st, partials, dgamma, dbeta, dbias, wgs, 3, n);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(fold)");

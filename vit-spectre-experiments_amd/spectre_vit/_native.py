@@ -28,14 +28,14 @@ SIGNATURES = {
     "spv_gemm_tn": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "spv_spectre_tail_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],
     "spv_spectre_tail_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i,
-                             c_i, c_f, c_u64, c_vp],
+                             c_i, c_f, c_u64, c_vp, c_vp],
     "spv_rowop_partial_floats": [c_i],
     "spv_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_add_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "spv_permut_gather_fwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_gather_bwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
-    "spv_fnet_mix": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp],
+    "spv_fnet_mix": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "spv_fnet_workspace_floats": [c_i, c_i, c_i],
     "spv_fnet_twiddle_floats": [c_i],
     "spv_fnet_make_twiddle": [c_vp, c_i, c_vp],

@@ -206,7 +206,8 @@ def _weight_grad(dh, x, rows, n, k, sink=None):
     dev = dh.device
     dw = _grad_buf(sink, (n, k), dev)
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
-    splits = max(1, min(1024 // tiles, (rows + 511) // 512))
+    # ~2 workgroups per CU: measured optimum on the 768 x 512 x 33280 weight gradient (21 splits: 51 us; 12: 69; 42: 56; 64: 64)
+    splits = max(1, min(512 // tiles, (rows + 511) // 512))
     ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev) if splits > 1 else None
     if dh.dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0:
         def launch():
@@ -257,6 +258,53 @@ def _new_seed():
 # ------------------------------------------------------------------------------------------------
 # SpectreLinear: GELU(LN(x W^T + b)) + avgpool(x) [+ dropout]      (reference layers.py:76-101)
 # ------------------------------------------------------------------------------------------------
+def _sl_forward(x2, weight, bias, gamma, beta, p_drop, out_fp32):
+    """raw SpectreLinear forward on a contiguous [rows, k] tensor -> (out [rows, n], saved-for-backward tuple)"""
+    n, k = weight.shape
+    rows = x2.shape[0]
+    dt = x2.dtype
+    mult = 8 if dt == torch.bfloat16 else 4
+    if n % mult or k % mult:
+        raise ValueError(f"SpectreLinear({k}->{n}) in {dt}: channel counts must be multiples of {mult}")
+    wc, wt = _shadows.get(weight, dt)
+    dev = x2.device
+    h = torch.empty((rows, n), dtype=dt, device=dev)
+    _gemm(x2, wc, bias, h, rows, n, k, k, k, n)
+    out = torch.empty((rows, n), dtype=torch.float32 if out_fp32 else dt, device=dev)
+    mean = torch.empty((rows,), dtype=torch.float32, device=dev)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=dev)
+    seed = _new_seed() if p_drop > 0.0 else 0
+    _native.call("spv_spectre_tail_fwd", _p(h), _p(x2), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, n, k,
+                 _dt(h), _dt(out), float(p_drop), seed, _stream())
+    sinks = (_sink(weight), _sink(bias), _sink(gamma), _sink(beta))
+    return out, (x2, h, mean, rstd, gamma, beta, wt, sinks, rows, n, k, float(p_drop), seed)
+
+
+def _sl_backward(dout2, saved, need_dx=True, dx_add=None):
+    """raw SpectreLinear backward -> (dx or None, dW, dbias, dgamma, dbeta); dx_add: a gradient of the same input that is
+    folded into dx by the tail kernel (saves a separate elementwise add)"""
+    x2, h, mean, rstd, gamma, beta, wt, sinks, rows, n, k, p_drop, seed = saved
+    dev = x2.device
+    if not dout2.is_contiguous():
+        dout2 = dout2.contiguous()
+    dh = torch.empty_like(h)
+    dx = torch.empty_like(x2)
+    s_w, s_b, s_g, s_be = sinks
+    dgamma = _grad_buf(s_g, (n,), dev)
+    dbeta = _grad_buf(s_be, (n,), dev)
+    dbias = _grad_buf(s_b, (n,), dev)
+    partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=dev)
+    _native.call("spv_spectre_tail_bwd", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
+                 _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
+                 _p(dx_add) if need_dx else 0, _stream())
+    if need_dx:
+        _gemm(dh, wt, None, dx, rows, k, n, n, wt.shape[1], k, accumulate=1)
+    else:
+        dx = None
+    dw = _weight_grad(dh, x2, rows, n, k, s_w)
+    return dx, dw, dbias, dgamma, dbeta
+
+
 class SpectreLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, p_drop, out_fp32):
@@ -266,54 +314,17 @@ class SpectreLinearFn(torch.autograd.Function):
         x2 = x.reshape(-1, k)
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        rows = x2.shape[0]
-        dt = x2.dtype
-        mult = 8 if dt == torch.bfloat16 else 4
-        if n % mult or k % mult:
-            raise ValueError(f"SpectreLinear({k}->{n}) in {dt}: channel counts must be multiples of {mult}")
-        wc, wt = _shadows.get(weight, dt)
-        dev = x2.device
-        h = torch.empty((rows, n), dtype=dt, device=dev)
-        _gemm(x2, wc, bias, h, rows, n, k, k, k, n)
-        out = torch.empty((rows, n), dtype=torch.float32 if out_fp32 else dt, device=dev)
-        mean = torch.empty((rows,), dtype=torch.float32, device=dev)
-        rstd = torch.empty((rows,), dtype=torch.float32, device=dev)
-        seed = _new_seed() if p_drop > 0.0 else 0
-        _native.call("spv_spectre_tail_fwd", _p(h), _p(x2), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, n, k,
-                     _dt(h), _dt(out), float(p_drop), seed, _stream())
-        ctx.save_for_backward(x2, h, mean, rstd, weight, gamma, beta)
-        ctx.wt = wt
-        ctx.sinks = (_sink(weight), _sink(bias), _sink(gamma), _sink(beta))
-        ctx.meta = (shape, rows, n, k, float(p_drop), seed)
+        out, saved = _sl_forward(x2, weight, bias, gamma, beta, p_drop, out_fp32)
+        ctx.saved = saved
+        ctx.shape = shape
         return out.reshape(*shape[:-1], n)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, h, mean, rstd, weight, gamma, beta = ctx.saved_tensors
-        shape, rows, n, k, p_drop, seed = ctx.meta
-        dev = x2.device
-        dt = x2.dtype
-        dout2 = dout.reshape(rows, n)
-        if not dout2.is_contiguous():
-            dout2 = dout2.contiguous()
-        dh = torch.empty_like(h)
-        dx = torch.empty_like(x2)
-        s_w, s_b, s_g, s_be = ctx.sinks
-        dgamma = _grad_buf(s_g, (n,), dev)
-        dbeta = _grad_buf(s_be, (n,), dev)
-        dbias = _grad_buf(s_b, (n,), dev)
-        partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=dev)
-        _native.call("spv_spectre_tail_bwd", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
-                     _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed, _stream())
-        wt = ctx.wt  # [k, ld] = W^T
-        ldt = wt.shape[1]
-        if ctx.needs_input_grad[0]:
-            _gemm(dh, wt, None, dx, rows, k, n, n, ldt, k, accumulate=1)
-            dx_out = dx.reshape(shape)
-        else:
-            dx_out = None
-        dw = _weight_grad(dh, x2, rows, n, k, s_w)
-        return dx_out, dw, dbias, dgamma, dbeta, None, None
+        saved = ctx.saved
+        rows, n = saved[8], saved[9]
+        dx, dw, dbias, dgamma, dbeta = _sl_backward(dout.reshape(rows, n), saved, ctx.needs_input_grad[0])
+        return (dx.reshape(ctx.shape) if dx is not None else None), dw, dbias, dgamma, dbeta, None, None
 
 
 def spectre_linear(x, weight, bias, gamma, beta, p_drop=0.0, out_fp32=False):
@@ -323,36 +334,44 @@ def spectre_linear(x, weight, bias, gamma, beta, p_drop=0.0, out_fp32=False):
 # ------------------------------------------------------------------------------------------------
 # residual + LayerNorm   mode 0: LN(a) + b (spectre.py:66)    mode 1: LN(a + b) (spectre.py:67)
 # ------------------------------------------------------------------------------------------------
+def _addln_forward(a2, b2, gamma, beta, mode):
+    rows, n = a2.shape
+    out = torch.empty_like(a2)
+    mean = torch.empty((rows,), dtype=torch.float32, device=a2.device)
+    rstd = torch.empty_like(mean)
+    _native.call("spv_add_layernorm_fwd", _p(a2), _p(b2), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, n, mode,
+                 _dt(a2), _stream())
+    return out, (a2, b2, mean, rstd, gamma, (_sink(gamma), _sink(beta)), rows, n, mode)
+
+
+def _addln_backward(d2, saved):
+    a2, b2, mean, rstd, gamma, sinks, rows, n, mode = saved
+    if not d2.is_contiguous():
+        d2 = d2.contiguous()
+    din = torch.empty_like(a2)
+    dgamma = _grad_buf(sinks[0], (n,), a2.device)
+    dbeta = _grad_buf(sinks[1], (n,), a2.device)
+    partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=a2.device)
+    _native.call("spv_add_layernorm_bwd", _p(d2), _p(a2), _p(b2), _p(mean), _p(rstd), _p(gamma), _p(din), _p(dgamma),
+                 _p(dbeta), _p(partials), rows, n, mode, _dt(a2), _stream())
+    return din, dgamma, dbeta
+
+
 class AddLayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, gamma, beta, mode):
         _require_gpu(a, b)
         n = a.shape[-1]
-        a2 = a.reshape(-1, n).contiguous()
-        b2 = b.reshape(-1, n).contiguous()
-        rows = a2.shape[0]
-        out = torch.empty_like(a2)
-        mean = torch.empty((rows,), dtype=torch.float32, device=a.device)
-        rstd = torch.empty_like(mean)
-        _native.call("spv_add_layernorm_fwd", _p(a2), _p(b2), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, n, mode,
-                     _dt(a2), _stream())
-        ctx.save_for_backward(a2, b2, mean, rstd, gamma)
-        ctx.sinks = (_sink(gamma), _sink(beta))
-        ctx.meta = (a.shape, rows, n, mode)
+        out, saved = _addln_forward(a.reshape(-1, n).contiguous(), b.reshape(-1, n).contiguous(), gamma, beta, mode)
+        ctx.saved = saved
+        ctx.shape = a.shape
         return out.reshape(a.shape)
 
     @staticmethod
     def backward(ctx, dout):
-        a2, b2, mean, rstd, gamma = ctx.saved_tensors
-        shape, rows, n, mode = ctx.meta
-        d2 = dout.reshape(rows, n).contiguous()
-        din = torch.empty_like(a2)
-        dgamma = _grad_buf(ctx.sinks[0], (n,), a2.device)
-        dbeta = _grad_buf(ctx.sinks[1], (n,), a2.device)
-        partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=a2.device)
-        _native.call("spv_add_layernorm_bwd", _p(d2), _p(a2), _p(b2), _p(mean), _p(rstd), _p(gamma), _p(din), _p(dgamma),
-                     _p(dbeta), _p(partials), rows, n, mode, _dt(a2), _stream())
-        din = din.reshape(shape)
+        rows, n, mode = ctx.saved[6], ctx.saved[7], ctx.saved[8]
+        din, dgamma, dbeta = _addln_backward(dout.reshape(rows, n), ctx.saved)
+        din = din.reshape(ctx.shape)
         return din, (dout if mode == 0 else din), dgamma, dbeta, None
 
 
@@ -409,7 +428,7 @@ def _fnet_twiddle(tokens, device):
     return t
 
 
-def _fnet_raw(x):
+def _fnet_raw(x, add_in=None):
     B, N, D = x.shape
     xc = x.contiguous()
     y = torch.empty_like(xc)
@@ -418,7 +437,7 @@ def _fnet_raw(x):
     tw = _fnet_twiddle(N, x.device)
 
     def launch():
-        _native.call("spv_fnet_mix", _p(xc), _p(y), _p(tw), B, N, D, _dt(xc), _p(ws), _stream())
+        _native.call("spv_fnet_mix", _p(xc), _p(y), _p(add_in), _p(tw), B, N, D, _dt(xc), _p(ws), _stream())
 
     if _timer is not None:
         _timer.bracket("fnet_mix", (B, N, D, _dt(xc)), launch)
@@ -713,3 +732,60 @@ class AttentionFn(torch.autograd.Function):
         _native.call("spv_attention_bwd", _p(d), _p(q), _p(probs), _p(ds), _p(dqkv), seqs, length, heads, hd, _dt(q), p_drop, seed,
                      _stream())
         return dqkv, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# fused halves of the encoder layer: same kernels, hand-written backward so that the residual-stream gradients are
+# folded into the producing kernels instead of being summed by separate elementwise passes
+# ------------------------------------------------------------------------------------------------
+class FFResidualFn(torch.autograd.Function):
+    """x2 = LayerNorm2(x1 + SpectreLinear3(SpectreLinear1(x1)))   (reference spectre.py:67,70-73)."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, b1, g1, be1, w3, b3, g3, be3, n2w, n2b, p_drop):
+        _require_gpu(x1, w1)
+        shape = x1.shape
+        x2d = x1.reshape(-1, shape[-1])
+        if not x2d.is_contiguous():
+            x2d = x2d.contiguous()
+        f1, s1 = _sl_forward(x2d, w1, b1, g1, be1, p_drop, False)
+        f3, s3 = _sl_forward(f1, w3, b3, g3, be3, p_drop, False)
+        out, sn = _addln_forward(f3, x2d, n2w, n2b, 1)
+        ctx.saved = (s1, s3, sn)
+        ctx.shape = shape
+        return out.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        s1, s3, sn = ctx.saved
+        rows, n = sn[6], sn[7]
+        ds, dn2w, dn2b = _addln_backward(dout.reshape(rows, n), sn)      # d(x1 + f3)
+        df1, dw3, db3, dg3, dbe3 = _sl_backward(ds, s3, True)
+        dx1, dw1, db1, dg1, dbe1 = _sl_backward(df1, s1, True, dx_add=ds)  # + the residual path, folded in
+        return dx1.reshape(ctx.shape), dw1, db1, dg1, dbe1, dw3, db3, dg3, dbe3, dn2w, dn2b, None
+
+
+class FNetResidualFn(torch.autograd.Function):
+    """x1 = LayerNorm1(Re(fft2(x))) + x   (reference spectre.py:66 with the 'fft_bare' mixer)."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b):
+        _require_gpu(x)
+        B, N, D = x.shape
+        xc = x.contiguous()
+        m = _fnet_raw(xc)
+        out, sn = _addln_forward(m.reshape(-1, D), xc.reshape(-1, D), n1w, n1b, 0)
+        ctx.saved = sn
+        ctx.shape = (B, N, D)
+        return out.reshape(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        sn = ctx.saved
+        B, N, D = ctx.shape
+        d2 = dout.reshape(-1, D)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        dm, dn1w, dn1b = _addln_backward(d2, sn)
+        dx = _fnet_raw(dm.reshape(B, N, D), add_in=d2)  # symmetric operator; + the residual gradient, folded in
+        return dx, dn1w, dn1b

@@ -66,9 +66,18 @@ class SpectreEncoderLayer(nn.Module):
 
     def forward(self, x):
         x = hip_ops.cast(x, hip_ops.compute_dtype(x))
-        x = hip_ops.add_layernorm(self.mix_layer(x), x, self.norm1.weight, self.norm1.bias, 0)
-        x = hip_ops.add_layernorm(self._ff_block(x), x, self.norm2.weight, self.norm2.bias, 1)
-        return x
+        if self.mixer == "fft":  # mixer + norm1 + residual as one autograd node (residual gradient folded into the FFT kernel)
+            x = hip_ops.FNetResidualFn.apply(x, self.norm1.weight, self.norm1.bias)
+        else:
+            x = hip_ops.add_layernorm(self.mix_layer(x), x, self.norm1.weight, self.norm1.bias, 0)
+        l1, l3 = self.linear1.local_head, self.linear3.local_head
+        mult = 8 if x.dtype == torch.bfloat16 else 4
+        if (l1[0].in_features % mult == 0 and l1[0].out_features % mult == 0):
+            # linear1 -> linear3 -> + x -> norm2 as one autograd node (spectre.py:67,70-73)
+            p = self.linear1.drop_p if self.training else 0.0
+            return hip_ops.FFResidualFn.apply(x, l1[0].weight, l1[0].bias, l1[1].weight, l1[1].bias, l3[0].weight, l3[0].bias,
+                                              l3[1].weight, l3[1].bias, self.norm2.weight, self.norm2.bias, p)
+        return hip_ops.add_layernorm(self._ff_block(x), x, self.norm2.weight, self.norm2.bias, 1)
 
     def _ff_block(self, x: torch.Tensor) -> torch.Tensor:
         return self.linear3(self.linear1(x))
