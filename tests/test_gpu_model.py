@@ -260,3 +260,29 @@ def test_vit_small_bf16_train_step(batch_first):
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters())
     spread = (out - out[0]).abs().max().item()
     assert (spread > 1e-3) == batch_first
+
+
+def test_base_224_distillation_step():
+    """BASELINE config 5 (student side): SpectreViT defaults (E768 L12 H12 F3072) at 224/16 -> N=197, d=151296 (gather
+    falls back to the global path, mix K = 9216), synthetic frozen teacher, distillation loss; bf16, bs 4."""
+    from spectre_vit.distillation import SyntheticTeacher, distillation_loss
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    torch.manual_seed(0)
+    m = SpectreViT(img_size=224, patch_size=16, in_channels=3, num_classes=100, num_encoders=2).to(dev())
+    teacher = SyntheticTeacher(100, 384, 3).to(dev())
+    x = torch.randn(4, 3, 224, 224, device=dev())
+    y = torch.randint(0, 100, (4,), device=dev())
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(3):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            s_logits, s_feat = m(x, return_features=True)
+        with torch.no_grad():
+            t_logits, _ = teacher(x, return_features=True)
+        loss, _, _ = distillation_loss(s_logits, t_logits, y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+        opt.step()
+        losses.append(loss.item())
+    assert s_feat.shape == (4, 768) and losses[-1] < losses[0], losses

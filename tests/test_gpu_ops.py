@@ -119,7 +119,7 @@ def sl_oracle(x, W, b, g, be, dy):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,lead", [(64, 64, (3, 7)), (256, 16, (2, 9)), (96, 64, (5, 3)), (64, 96, (4, 5)),
                                            (512, 768, (2, 65)), (768, 512, (2, 65)), (512, 104, (33,)), (1024, 64, (130,)),
-                                           (48, 256, (3, 50))])
+                                           (48, 256, (3, 50)), (64, 256, (9,)), (768, 3072, (5,)), (3072, 768, (5,))])
 def test_spectre_linear(ops, dtype, cin, cout, lead):
     rng = np.random.default_rng(cin * 7 + cout)
     x = q(rng.standard_normal(lead + (cin,)), dtype)

@@ -17,7 +17,7 @@ constexpr int BWD_MAX_WG = 1024;  // backward grids are capped here: one partial
 
 // how the avg-pool skip maps channels: identity, exact windows of k_in/n inputs, or the general
 // overlapping/up-sampling windows (tables built once per workgroup in LDS, no per-element division)
-enum PoolMode { POOL_IDENT = 0, POOL_EXACT = 1, POOL_TABLE = 2 };
+enum PoolMode { POOL_IDENT = 0, POOL_EXACT = 1, POOL_TABLE = 2, POOL_REPEAT = 3 };  // REPEAT: n = r * k_in, out[c] = x[c / r]
 
 template <int VEC> __device__ __forceinline__ void ldv(const void* base, size_t off, int bf, float (&v)[VEC]);
 template <> __device__ __forceinline__ void ldv<4>(const void* base, size_t off, int bf, float (&v)[4]) {
@@ -175,6 +175,10 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_kernel(const void* __restrict_
             ldv<VEC>(beta, e0, 0, b);
             if (pool_mode == POOL_IDENT) {
                 ldv<VEC>(x, (size_t)row * k_in + e0, bf, pv);
+            } else if (pool_mode == POOL_REPEAT) {
+                const int rr = n / k_in;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) pv[k] = ld1(x, (size_t)row * k_in + (e0 + k) / rr, bf);
             } else if (pool_mode == POOL_EXACT) {
                 // this lane's VEC outputs average VEC*pw contiguous inputs
                 const size_t xb = (size_t)row * k_in + (size_t)e0 * pw;
@@ -350,6 +354,19 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict_
                     if (p_drop > 0.0f) d *= dropout_scale(rkey, (unsigned)c, p_drop, inv_keep);
                     st1(dxp, (size_t)row * k_in + j, bf, d * inv_pw + (dx_add ? ld1(dx_add, (size_t)row * k_in + j, bf) : 0.0f));
                 }
+            }
+        } else if (pool_mode == POOL_REPEAT) {
+            // every input j fed n / k_in outputs with weight 1
+            const int rr = n / k_in;
+            for (int j = lane; j < k_in; j += 64) {
+                float a = 0.0f;
+                for (int c = j * rr; c < (j + 1) * rr; ++c) {
+                    float d = ld1(dout, (size_t)row * n + c, dout_bf);
+                    if (p_drop > 0.0f) d *= dropout_scale(rkey, (unsigned)c, p_drop, inv_keep);
+                    a += d;
+                }
+                if (dx_add != nullptr) a += ld1(dx_add, (size_t)row * k_in + j, bf);
+                st1(dxp, (size_t)row * k_in + j, bf, a);
             }
         } else if (pool_mode == POOL_TABLE) {
             // transposed pooling: input j receives dout[c] / width(c) from every window c that covers j
@@ -716,7 +733,9 @@ inline bool pick_cfg(int n, RowCfg& c) {
     } while (0)
 
 inline int check_dtype(int d) { return d == SPV_F32 || d == SPV_BF16; }
-inline int pool_mode_of(int n, int k_in) { return k_in == n ? POOL_IDENT : (k_in % n == 0 ? POOL_EXACT : POOL_TABLE); }
+inline int pool_mode_of(int n, int k_in) {
+    return k_in == n ? POOL_IDENT : (k_in % n == 0 ? POOL_EXACT : (n % k_in == 0 ? POOL_REPEAT : POOL_TABLE));
+}
 
 }  // namespace
 
