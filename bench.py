@@ -63,6 +63,30 @@ def cpu_baseline(mixer, seconds_budget=20.0):
                 sample=f"numpy fp32 oracle, {n} train steps of bs {bs} (same model/mixer, dropout 0), {dt:.2f} s/step")
 
 
+def attach_pmc_traffic(roof, mixer):
+    """roofline.traffic = measured HBM bytes per launch of the dominant kernel, from the newest committed rocprofv3 PMC
+    collection (tools/collect_pmc.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note
+    in MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, hence the committed file."""
+    import glob
+    if not roof:
+        return
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{mixer}_pmc_traffic.json")))
+    if not files:
+        return
+    data = json.load(open(files[-1]))
+    if roof["kernel"] == "gemm":
+        M, N, K = roof["shape"]
+        nt_grid = ((M + 127) // 128) * ((N + 127) // 128) * 256
+        cands = [e for e in data["kernels"] if e["kernel"].startswith("gemm_nt") and e["grid_size"] == nt_grid]
+        cands += [e for e in data["kernels"] if e["kernel"].startswith("gemm_tn") and e["grid_size"] % nt_grid == 0 and K > 4096]
+    else:
+        B = roof["shape"][0]
+        cands = [e for e in data["kernels"] if e["kernel"].startswith("fnet_mfma") and e["grid_size"] == B * 512]
+    if cands:
+        roof["traffic"] = cands[0]["hbm_bytes_corrected"]
+        roof["traffic_source"] = os.path.basename(files[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +198,7 @@ def main():
         if timer is not None:
             rec["roofline"] = timer.roofline()
             rec["kernels"] = timer.summary()
+            attach_pmc_traffic(rec["roofline"], args.mixer)
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.mixer)
         print(json.dumps(rec), flush=True)
