@@ -60,6 +60,12 @@ int spv_gemm_nt_grouped_rows(const void* A, const void* B, const float* bias, co
                              int N, int K, int lda, int ldb, int ldc, int in_dtype, int out_dtype,
                              int rows_per_group, int group_stride, int row_offset, void* stream);
 
+/* Data gradient of a SpectreLinear whose skip pools exact windows (in = pool_window * out, the MHPermutMix linear,
+ * layers.py:66,93): C[M,N] = A[M,K] . B[N,K]^T + dout[M, N/pool_window][.., n / pool_window] / pool_window -- the
+ * transposed average pooling is added in the epilogue instead of going through a rows x N buffer. */
+int spv_gemm_nt_pool_bwd(const void* A, const void* B, void* C, const void* dout, int pool_window, int M, int N, int K,
+                         int lda, int ldb, int ldc, int in_dtype, int out_dtype, int dout_dtype, void* stream);
+
 /* TN contraction C[M,N] = sum_k A[k][m] B[k][n], A [K,lda>=M], B [K,ldb>=N] row-major bf16: the weight gradient
  * dW = dh^T . x (backward of layers.py:86) straight from the row-major activations (transposing LDS reads,
  * ds_read_b64_tr_b16); M, N, lda, ldb multiples of 8; split-K as above. */
@@ -105,8 +111,10 @@ int spv_add_layernorm_bwd(const void* dout, const void* a, const void* b, const 
  * no atomics, head by head in LDS). */
 /* idx: uint32 [2][heads][d] -- [0] forward table (perm | sign), [1] inverse table (inverse perm | sign). */
 int spv_permut_pack(const int64_t* perms, const float* signs, uint32_t* idx, int heads, int d, void* stream);
-int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g, int batch, int heads, int d,
-                          int dtype, void* stream);
+/* pooled (nullable, [batch, heads*d / pool_window]): the average of every pool_window consecutive gathered elements
+ * (what the SpectreLinear skip needs), produced on the fly so the tail kernel does not re-read g. */
+int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g, void* pooled, int pool_window, int batch,
+                          int heads, int d, int dtype, void* stream);
 int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* dx, int batch, int heads, int d,
                           int dtype, void* stream);
 

@@ -286,3 +286,33 @@ def test_base_224_distillation_step():
         opt.step()
         losses.append(loss.item())
     assert s_feat.shape == (4, 768) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mh_permut_mix_full_width_vs_oracle(dtype):
+    """MHPermutMix at the Small width (N 65, E 512, H 16: pooled-gather + pooled-broadcast dgrad fast paths) vs the oracle."""
+    from spectre_vit.models.spectre.layers import MHPermutMix
+    torch.manual_seed(3)
+    m = MHPermutMix(512, 65, 16, 512).to(dev())
+    with torch.no_grad():
+        m.linear.local_head[1].weight.uniform_(0.5, 1.5)
+        m.linear.local_head[1].bias.normal_(0, 0.1)
+    x = torch.randn(4, 65, 512, device=dev())
+    dy = torch.randn(4, 65, 512, device=dev())
+    xq = x.to(dtype)
+    xin = xq.clone().requires_grad_(True)
+    y = m(xin)
+    y.backward(dy.to(dtype))
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    f = lambda k: sd[k].astype(np.float64)
+    wq = n64(t(sd["linear.local_head.0.weight"], dtype))
+    p = dict(perms=sd["perms"], signs=f("signs"), linear=dict(weight=wq, bias=f("linear.local_head.0.bias"),
+             ln_weight=f("linear.local_head.1.weight"), ln_bias=f("linear.local_head.1.bias")))
+    ref, cache = O.mh_permut_mix_fwd(n64(xq), p)
+    dx_ref, gr = O.mh_permut_mix_bwd(n64(dy.to(dtype)), p, cache)
+    tol = 5e-5 if dtype == torch.float32 else 3e-2
+    check(y, ref, tol, "y")
+    check(xin.grad, dx_ref, tol * 2, "dx")
+    check(m.linear.local_head[0].weight.grad, gr["linear"]["weight"], tol * 2, "dW")
+    check(m.linear.local_head[1].weight.grad, gr["linear"]["ln_weight"], tol * 2, "dgamma")
+    check(m.linear.local_head[0].bias.grad, gr["linear"]["bias"], tol * 2, "dbias")

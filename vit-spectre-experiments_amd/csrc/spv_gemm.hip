@@ -46,7 +46,8 @@ template <typename TO>
 __device__ __forceinline__ void store_acc_tile(f32x16 (&acc)[2][2], unsigned char* smem, const float* __restrict__ bias,
                                                TO* __restrict__ C, float* __restrict__ ws, int M, int N, int ldc, int accumulate,
                                                int m0, int n0, int split, int rg, int gs, int roff,
-                                               const float* __restrict__ bias2d) {
+                                               const float* __restrict__ bias2d, const void* __restrict__ bc = nullptr,
+                                               int bc_pw = 0, int bc_bf = 0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, fh = lane >> 5;
     float* stage = reinterpret_cast<float*>(smem + wave * 9216);  // 9216 B per wave >= 32 * 68 * 4
@@ -93,6 +94,27 @@ __device__ __forceinline__ void store_acc_tile(f32x16 (&acc)[2][2], unsigned cha
                 if (bias2d) b2 = bias2d + (size_t)(row % rg) * N + col0;
             }
             TO* cp = C + (size_t)orow * ldc + col0;
+            if (bc != nullptr) {
+                // + P[row][col / pw] / pw: the transposed exact-window pooling of the SpectreLinear skip (backward of
+                // layers.py:93,101) broadcast straight into the data gradient instead of a rows x K buffer written by the
+                // tail kernel and re-read here
+                const float sc = 1.0f / (float)bc_pw;
+                const int ldp = N / bc_pw;
+                if ((bc_pw & 7) == 0) {  // the lane's 8 columns lie in one window: one load, one divide
+                    const size_t o = (size_t)row * ldp + col0 / bc_pw;
+                    const float t = (bc_bf ? bf2f(static_cast<const bf16_t*>(bc)[o]) : static_cast<const float*>(bc)[o]) * sc;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] += t;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (u < nvalid) {
+                            const size_t o = (size_t)row * ldp + (col0 + u) / bc_pw;
+                            v[u] += (bc_bf ? bf2f(static_cast<const bf16_t*>(bc)[o]) : static_cast<const float*>(bc)[o]) * sc;
+                        }
+                    }
+                }
+            }
             if (nvalid == 8 && vec_c) {
                 if (bias != nullptr) {
                     const float4 b0 = *reinterpret_cast<const float4*>(bias + col0), b1 = *reinterpret_cast<const float4*>(bias + col0 + 4);
@@ -144,7 +166,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
                                                       float* __restrict__ ws, int M, int N, int K, int lda,
                                                       int ldb, int ldc, int k_per_split, int accumulate,
                                                       int tiles_n, int tiles_mn, int nsplit, int rg, int gs, int roff,
-                                                      const float* __restrict__ bias2d) {
+                                                      const float* __restrict__ bias2d, const void* __restrict__ bc, int bc_pw,
+                                                      int bc_bf) {
     constexpr int BK = KT<T>::BK;
     constexpr int CH = KT<T>::CH;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * ROWB];
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
         __syncthreads();
     }
 
-    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d);
+    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -274,7 +297,8 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
                                                            float* __restrict__ ws, int M, int N, int K, int lda, int ldb,
                                                            int ldc, int k_per_split, int accumulate, int tiles_n,
                                                            int tiles_mn, int nsplit, int rg, int gs, int roff,
-                                                           const float* __restrict__ bias2d) {
+                                                           const float* __restrict__ bias2d, const void* __restrict__ bc,
+                                                           int bc_pw, int bc_bf) {
     constexpr int CPR = KB / 16;              // 16-byte chunks per tile row
     constexpr int RPI = 64 / CPR;             // tile rows written by one wave instruction (1 KiB)
     constexpr int IPW = (BM / RPI) / 4;       // DMA instructions per wave per operand per stage
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
-    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d);
+    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -479,7 +503,7 @@ inline int kend_len(int K, int k_per_split) { return K < k_per_split ? K : k_per
 template <typename T, typename TO>
 int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb,
                 int ldc, int accumulate, int splits, void* workspace, hipStream_t st, int rg = 0, int gs = 0, int roff = 0,
-                const float* bias2d = nullptr) {
+                const float* bias2d = nullptr, const void* bc = nullptr, int bc_pw = 0, int bc_bf = 0) {
     constexpr int BK = KT<T>::BK;
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
     int k_per_split = K;
@@ -499,18 +523,18 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
             if (kb == 64)
                 hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 64>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                    static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                                   accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d);
+                                   accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
             else
                 hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 128>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                    static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                                   accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d);
+                                   accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
             SPV_LAUNCH_CHECK("spv_gemm_nt(glds)");
             goto reduce;
         }
     }
     hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), grid, dim3(256), 0, st, static_cast<const T*>(A),
                        static_cast<const T*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                       accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d);
+                       accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
     SPV_LAUNCH_CHECK("spv_gemm_nt");
 reduce:
     if (splits > 1) {
@@ -526,7 +550,16 @@ reduce:
 
 static int gemm_entry(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int in_dtype, int out_dtype, int accumulate, int splits, void* workspace, void* stream, int rg, int gs,
-                      int roff, const float* bias2d);
+                      int roff, const float* bias2d, const void* bc = nullptr, int bc_pw = 0, int bc_bf = 0);
+
+extern "C" int spv_gemm_nt_pool_bwd(const void* A, const void* B, void* C, const void* dout, int pool_window, int M, int N, int K,
+                                    int lda, int ldb, int ldc, int in_dtype, int out_dtype, int dout_dtype, void* stream) {
+    SPV_CHECK(dout != nullptr && pool_window > 0 && N % pool_window == 0, "spv_gemm_nt_pool_bwd: bad pooling window %d for N=%d",
+              pool_window, N);
+    SPV_CHECK(dout_dtype == SPV_F32 || dout_dtype == SPV_BF16, "spv_gemm_nt_pool_bwd: bad dout dtype");
+    return gemm_entry(A, B, nullptr, C, M, N, K, lda, ldb, ldc, in_dtype, out_dtype, 0, 1, nullptr, stream, 0, 0, 0, nullptr, dout,
+                      pool_window, dout_dtype == SPV_BF16);
+}
 
 extern "C" int spv_gemm_nt(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb,
                            int ldc, int in_dtype, int out_dtype, int accumulate, int splits, void* workspace, void* stream) {
@@ -545,7 +578,7 @@ extern "C" int spv_gemm_nt_grouped_rows(const void* A, const void* B, const floa
 
 static int gemm_entry(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int in_dtype, int out_dtype, int accumulate, int splits, void* workspace, void* stream, int rg, int gs,
-                      int roff, const float* bias2d) {
+                      int roff, const float* bias2d, const void* bc, int bc_pw, int bc_bf) {
     SPV_CHECK(M > 0 && N > 0 && K > 0, "spv_gemm_nt: empty problem M=%d N=%d K=%d", M, N, K);
     SPV_CHECK(in_dtype == SPV_F32 || in_dtype == SPV_BF16, "spv_gemm_nt: bad in_dtype %d", in_dtype);
     SPV_CHECK(out_dtype == SPV_F32 || out_dtype == SPV_BF16, "spv_gemm_nt: bad out_dtype %d", out_dtype);
@@ -559,12 +592,12 @@ static int gemm_entry(const void* A, const void* B, const float* bias, void* C, 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (in_dtype == SPV_BF16) {
         if (out_dtype == SPV_BF16)
-            return launch_gemm<bf16_t, bf16_t>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d);
-        return launch_gemm<bf16_t, float>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d);
+            return launch_gemm<bf16_t, bf16_t>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
+        return launch_gemm<bf16_t, float>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
     }
     if (out_dtype == SPV_BF16)
-        return launch_gemm<float, bf16_t>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d);
-    return launch_gemm<float, float>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d);
+        return launch_gemm<float, bf16_t>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
+    return launch_gemm<float, float>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
 }
 
 extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,

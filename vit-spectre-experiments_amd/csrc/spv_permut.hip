@@ -35,7 +35,7 @@ template <> struct raw<bf16_t> { using type = uint16_t; static constexpr uint32_
 // forward, LDS path: grid = batch
 template <typename T>
 __global__ __launch_bounds__(PT) void gather_fwd_lds_kernel(const T* __restrict__ x, const uint32_t* __restrict__ idx,
-                                                            T* __restrict__ g, int heads, int d) {
+                                                            T* __restrict__ g, int heads, int d, T* __restrict__ pooled, int pw) {
     using R = typename raw<T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     R* row = reinterpret_cast<R*>(smem);
@@ -63,6 +63,20 @@ __global__ __launch_bounds__(PT) void gather_fwd_lds_kernel(const T* __restrict_
             reinterpret_cast<uint2*>(go)[q] = w;
         } else {
             reinterpret_cast<uint4*>(go)[q] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        if (pooled != nullptr) {
+            // the SpectreLinear skip averages pw consecutive gathered elements (layers.py:93,101): this lane has 4 of them,
+            // pw / 4 neighbouring lanes (consecutive q) the rest -> DPP quad / row reduction, first lane of the group writes
+            float sm;
+            if constexpr (sizeof(T) == 2)
+                sm = (bf2f(o[0]) + bf2f(o[1])) + (bf2f(o[2]) + bf2f(o[3]));
+            else
+                sm = (__uint_as_float(o[0]) + __uint_as_float(o[1])) + (__uint_as_float(o[2]) + __uint_as_float(o[3]));
+            const int gl = pw >> 2;  // lanes per window: 1, 2, 4 or 8 (host checks)
+            if (gl >= 2) sm += dpp_mov<0xB1>(sm);   // quad_perm [1,0,3,2]
+            if (gl >= 4) sm += dpp_mov<0x4E>(sm);   // quad_perm [2,3,0,1]
+            if (gl >= 8) sm += dpp_mov<0x124>(sm);  // row_ror:4 -> lanes 0-3 also hold lanes 4-7's sum
+            if ((q & (gl - 1)) == 0) io<T>::st(pooled + (size_t)b * (total / pw) + q / gl, sm * (1.0f / (float)pw));
         }
     }
     for (int64_t f = (t4 << 2) + threadIdx.x; f < total; f += PT) {
@@ -173,21 +187,28 @@ extern "C" int spv_permut_pack(const int64_t* perms, const float* signs, uint32_
     return 0;
 }
 
-extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g, int batch, int heads, int d, int dtype,
-                                     void* stream) {
+extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g, void* pooled, int pool_window, int batch,
+                                     int heads, int d, int dtype, void* stream) {
     SPV_CHECK(batch > 0 && heads > 0 && d > 0, "spv_permut_gather_fwd: empty");
     SPV_CHECK(dtype == SPV_F32 || dtype == SPV_BF16, "spv_permut_gather_fwd: bad dtype %d", dtype);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t es = dtype == SPV_BF16 ? 2 : 4;
     const bool aligned = ((size_t)d * es) % 16 == 0 && ((int64_t)heads * d) % 4 == 0;
+    if (pooled != nullptr) {
+        const int64_t total = (int64_t)heads * d;
+        SPV_CHECK(aligned && (size_t)d * es <= (size_t)LDS_LIMIT, "spv_permut_gather_fwd: pooled output needs the LDS path");
+        SPV_CHECK((pool_window == 4 || pool_window == 8 || pool_window == 16 || pool_window == 32) && total % pool_window == 0 &&
+                      (total / 4) % PT == 0,
+                  "spv_permut_gather_fwd: unsupported pool window %d", pool_window);
+    }
     if (aligned && (size_t)d * es <= (size_t)LDS_LIMIT) {
         const size_t lds = (size_t)d * es;
         if (dtype == SPV_BF16) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-            hipLaunchKernelGGL((gather_fwd_lds_kernel<bf16_t>), dim3(batch), dim3(PT), lds, st, (const bf16_t*)x, idx, (bf16_t*)g, heads, d);
+            hipLaunchKernelGGL((gather_fwd_lds_kernel<bf16_t>), dim3(batch), dim3(PT), lds, st, (const bf16_t*)x, idx, (bf16_t*)g, heads, d, (bf16_t*)pooled, pool_window);
         } else {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
-            hipLaunchKernelGGL((gather_fwd_lds_kernel<float>), dim3(batch), dim3(PT), lds, st, (const float*)x, idx, (float*)g, heads, d);
+            hipLaunchKernelGGL((gather_fwd_lds_kernel<float>), dim3(batch), dim3(PT), lds, st, (const float*)x, idx, (float*)g, heads, d, (float*)pooled, pool_window);
         }
     } else {
         dim3 grid((unsigned)std::min<int64_t>(((int64_t)heads * d + 255) / 256, 1024), batch);

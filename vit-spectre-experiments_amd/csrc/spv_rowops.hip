@@ -328,7 +328,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict_
             }
             stv<VEC>(dh, (size_t)row * n + e0, bf, o);
         }
-        if (pool_mode == POOL_EXACT) {
+        if (pool_mode == POOL_EXACT && dxp != nullptr) {  // dxp == nullptr: the data-gradient GEMM adds this term in its epilogue
             // transposed pooling, exact windows: input j receives dout[j / pw] / pw
             if (VEC == 4 && (pw & 3) == 0) {
                 for (int j0 = lane * 4; j0 < k_in; j0 += 256) {

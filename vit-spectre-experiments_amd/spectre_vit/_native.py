@@ -33,7 +33,8 @@ SIGNATURES = {
     "spv_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_add_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
-    "spv_permut_gather_fwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "spv_permut_gather_fwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "spv_gemm_nt_pool_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_gather_bwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_fnet_mix": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "spv_fnet_workspace_floats": [c_i, c_i, c_i],

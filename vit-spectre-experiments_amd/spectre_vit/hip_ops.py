@@ -410,7 +410,7 @@ class PermutGatherFn(torch.autograd.Function):
         xc = x.contiguous()
         d = xc.numel() // B
         g = torch.empty((B, heads * d), dtype=x.dtype, device=x.device)
-        _native.call("spv_permut_gather_fwd", _p(xc), _p(idx), _p(g), B, heads, d, _dt(xc), _stream())
+        _native.call("spv_permut_gather_fwd", _p(xc), _p(idx), _p(g), 0, 0, B, heads, d, _dt(xc), _stream())
         ctx.idx = idx
         ctx.meta = (x.shape, B, heads, d)
         return g
@@ -801,3 +801,80 @@ class FNetResidualFn(torch.autograd.Function):
         dm, dn1w, dn1b = _addln_backward(d2, sn)
         dx = _fnet_raw(dm.reshape(B, N, D), add_in=d2)  # symmetric operator; + the residual gradient, folded in
         return dx, dn1w, dn1b
+
+
+class PermutMixFn(torch.autograd.Function):
+    """MHPermutMix as one autograd node: SpectreLinear(gather(x)) (reference layers.py:68-73).
+
+    Forward: the gather kernel also emits the averages of every `heads` consecutive gathered elements, which is exactly
+    the SpectreLinear skip (AdaptiveAvgPool1d(E) over E*heads channels), so the tail kernel does not re-read the 16x larger
+    gathered tensor.  Backward: the transposed pooling is added in the data-gradient GEMM's epilogue instead of being
+    written to and re-read from a (B*N, E*heads) buffer."""
+
+    @staticmethod
+    def forward(ctx, x, idx, heads, weight, bias, gamma, beta):
+        _require_gpu(x, weight)
+        B = x.shape[0]
+        xc = x.contiguous()
+        d = xc.numel() // B
+        n, k = weight.shape
+        total = heads * d
+        rows = (B * total) // k
+        dt = xc.dtype
+        mult = 8 if dt == torch.bfloat16 else 4
+        if n % mult or k % mult:
+            raise ValueError(f"MHPermutMix linear ({k}->{n}) in {dt}: channel counts must be multiples of {mult}")
+        pw = k // n if k % n == 0 else 0
+        es = 2 if dt == torch.bfloat16 else 4
+        can_pool = pw in (4, 8, 16, 32) and (d * es) % 16 == 0 and d * es <= 150 * 1024 and (total // 4) % 1024 == 0 and total % pw == 0
+        dev = xc.device
+        g = torch.empty((rows, k), dtype=dt, device=dev)
+        pooled = torch.empty((rows, n), dtype=dt, device=dev) if can_pool else None
+        st = _stream()
+        _native.call("spv_permut_gather_fwd", _p(xc), _p(idx), _p(g), _p(pooled), pw, B, heads, d, _dt(xc), st)
+        wc, wt = _shadows.get(weight, dt)
+        h = torch.empty((rows, n), dtype=dt, device=dev)
+        _gemm(g, wc, bias, h, rows, n, k, k, k, n)
+        out = torch.empty((rows, n), dtype=dt, device=dev)
+        mean = torch.empty((rows,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=dev)
+        skip = pooled if can_pool else g
+        _native.call("spv_spectre_tail_fwd", _p(h), _p(skip), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, n,
+                     n if can_pool else k, _dt(h), _dt(out), 0.0, 0, st)
+        ctx.save_for_backward(g, h, mean, rstd, gamma, beta)
+        ctx.aux = (idx, wt, (_sink(weight), _sink(bias), _sink(gamma), _sink(beta)), x.shape, B, heads, d, rows, n, k, pw)
+        return out.reshape(B, rows // B, n)
+
+    @staticmethod
+    def backward(ctx, dout):
+        g, h, mean, rstd, gamma, beta = ctx.saved_tensors
+        idx, wt, sinks, xshape, B, heads, d, rows, n, k, pw = ctx.aux
+        dev = g.device
+        st = _stream()
+        d2 = dout.reshape(rows, n)
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        s_w, s_b, s_g, s_be = sinks
+        dh = torch.empty_like(h)
+        dgamma = _grad_buf(s_g, (n,), dev)
+        dbeta = _grad_buf(s_be, (n,), dev)
+        dbias = _grad_buf(s_b, (n,), dev)
+        partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=dev)
+        dg = torch.empty_like(g)
+        fast = pw > 0
+        _native.call("spv_spectre_tail_bwd", _p(d2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), 0 if fast else _p(dg),
+                     _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(d2), 0.0, 0, 0, st)
+        if fast:
+            def launch():
+                _native.call("spv_gemm_nt_pool_bwd", _p(dh), _p(wt), _p(dg), _p(d2), pw, rows, k, n, n, wt.shape[1], k, _dt(dh),
+                             _dt(dg), _dt(d2), st)
+            if _timer is not None:
+                _timer.bracket("gemm", (rows, k, n, _dt(dh)), launch)
+            else:
+                launch()
+        else:
+            _gemm(dh, wt, None, dg, rows, k, n, n, wt.shape[1], k, accumulate=1)
+        dw = _weight_grad(dh, g, rows, n, k, s_w)
+        dx = torch.empty((B, d), dtype=g.dtype, device=dev)
+        _native.call("spv_permut_gather_bwd", _p(dg), _p(idx), _p(dx), B, heads, d, _dt(dg), st)
+        return dx.reshape(xshape), None, None, dw, dbias, dgamma, dbeta

@@ -85,6 +85,11 @@ class MHPermutMix(nn.Module):
     def forward(self, x):
         B = x.shape[0]
         x = hip_ops.cast(x, hip_ops.compute_dtype(x))
+        lin, ln = self.linear.local_head[0], self.linear.local_head[1]
+        mult = 8 if x.dtype == torch.bfloat16 else 4
+        if lin.in_features % mult == 0 and lin.out_features % mult == 0:
+            # gather + Linear + LayerNorm/GELU/avg-pool skip as one autograd node
+            return hip_ops.PermutMixFn.apply(x, self._table(), self.num_heads, lin.weight, lin.bias, ln.weight, ln.bias)
         g = hip_ops.PermutGatherFn.apply(x, self._table(), self.num_heads)
         return self.linear(g.view(B, self.token_dim, self.concat_dim))
 
