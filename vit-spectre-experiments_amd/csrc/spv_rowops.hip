@@ -2,10 +2,11 @@
 // skip -> dropout) and residual + LayerNorm, forward and backward.  HBM-bandwidth bound.
 //
 // Mapping: one wave64 per row, the whole row cached in registers (VEC contiguous elements per lane per
-// step, 16 B / 8 B vector accesses for VEC = 4), wave shuffles for the two LayerNorm reductions, fp32
-// statistics.  Column reductions of the backward (dgamma, dbeta, dbias) are carried in registers across
-// the rows a wave owns, folded across the 8 waves of a workgroup through LDS in a fixed order, written
-// as one slab per workgroup and folded by a second tiny kernel: deterministic, no atomics.
+// step, 16 B / 8 B vector accesses for VEC = 4), DPP reductions for the two LayerNorm sums, fp32
+// statistics.  Column reductions of the backward (dgamma, dbeta, dbias) are carried across the rows a wave
+// owns (registers in the generic kernels, per-wave LDS slots in the lane-contiguous ones), folded across
+// the 4 waves of a workgroup through LDS in a fixed order, written as one slab per workgroup and folded by
+// a second small kernel: deterministic, no atomics.
 #include "spv_common.h"
 
 namespace {
@@ -102,7 +103,7 @@ __device__ __forceinline__ void write_partials(float (&acc)[NP][MAXI][VEC], floa
 
 // ------------------------------------------------------------------------------------------------
 template <int VEC, int MAXI, bool FASTG>
-__global__ __launch_bounds__(RT, 4) void tail_fwd_kernel(const void* __restrict__ h, const void* __restrict__ x,
+__global__ __launch_bounds__(RT, (MAXI <= 4 ? 4 : (MAXI <= 12 ? 2 : 1))) void tail_fwd_kernel(const void* __restrict__ h, const void* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        void* __restrict__ out, float* __restrict__ mean_o,
                                                        float* __restrict__ rstd_o, int rows, int n, int k_in, int bf,
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_kernel(const void* __restrict_
 }
 
 template <int VEC, int MAXI, bool FASTG>
-__global__ __launch_bounds__(RT, 4) void tail_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ h,
+__global__ __launch_bounds__(RT, (MAXI <= 4 ? 4 : (MAXI <= 12 ? 2 : 1))) void tail_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ h,
                                                        const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        void* __restrict__ dh, void* __restrict__ dxp,
@@ -494,33 +495,42 @@ __global__ __launch_bounds__(RT) void addln_bwd_kernel(const void* __restrict__ 
     write_partials<VEC, MAXI, 2>(acc, lds, partials + (size_t)blockIdx.x * 2 * n, n, lane, wave);
 }
 
-// out[p][c] = sum_w partials[w][p][c]; a workgroup owns 32 columns, 8 thread rows split the slabs, fixed order
-__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partials, float* __restrict__ o0,
-                                                            float* __restrict__ o1, float* __restrict__ o2, int parts, int np,
-                                                            int n) {
-    __shared__ float red[8][33];
-    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+// out[p][c] = sum_w partials[w][p][c]; a workgroup of 1024 threads owns 16 columns (64-byte segments), 64 thread rows
+// split the slabs (<= 16 loads each at 1024 slabs: the kernel is latency bound, so the loads must be spread thin),
+// fixed summation order
+constexpr int FOLD_COLS = 16, FOLD_ROWS = 64;
+__global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void fold_partials_kernel(const float* __restrict__ partials, float* __restrict__ o0,
+                                                                             float* __restrict__ o1, float* __restrict__ o2,
+                                                                             int parts, int np, int n) {
+    __shared__ float red[FOLD_ROWS][FOLD_COLS + 1];
+    const int cx = threadIdx.x % FOLD_COLS, py = threadIdx.x / FOLD_COLS;
+    const int c = blockIdx.x * FOLD_COLS + cx;
     const int total = np * n;
     float s = 0.0f;
     if (c < total) {
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
         int w = py;
-        for (; w + 24 < parts; w += 32) {
+        for (; w + 3 * FOLD_ROWS < parts; w += 4 * FOLD_ROWS) {
             s0 += partials[(size_t)w * total + c];
-            s1 += partials[(size_t)(w + 8) * total + c];
-            s2 += partials[(size_t)(w + 16) * total + c];
-            s3 += partials[(size_t)(w + 24) * total + c];
+            s1 += partials[(size_t)(w + FOLD_ROWS) * total + c];
+            s2 += partials[(size_t)(w + 2 * FOLD_ROWS) * total + c];
+            s3 += partials[(size_t)(w + 3 * FOLD_ROWS) * total + c];
         }
-        for (; w < parts; w += 8) s0 += partials[(size_t)w * total + c];
+        for (; w < parts; w += FOLD_ROWS) s0 += partials[(size_t)w * total + c];
         s = (s0 + s1) + (s2 + s3);
     }
     red[py][cx] = s;
     __syncthreads();
-    if (py == 0 && c < total) {
+    // 64 -> 4 -> 1 in a fixed order
+    if (py < 4) {
         float t = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t += red[q][cx];
+        for (int q = 0; q < FOLD_ROWS / 4; ++q) t += red[py * (FOLD_ROWS / 4) + q][cx];
+        red[py * (FOLD_ROWS / 4)][cx] = t;
+    }
+    __syncthreads();
+    if (py == 0 && c < total) {
+        const float t = (red[0][cx] + red[FOLD_ROWS / 4][cx]) + (red[FOLD_ROWS / 2][cx] + red[3 * FOLD_ROWS / 4][cx]);
         const int p = c / n, cc = c % n;
         float* o = p == 0 ? o0 : (p == 1 ? o1 : o2);
         if (o) o[cc] = t;
@@ -603,56 +613,72 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
     }
 }
 
+// Column sums (dgamma, dbeta, dbias) live in LDS, not registers: 3*CO accumulators per lane pushed the register count
+// past the 4-waves/SIMD budget (spills).  Each wave owns [3][CO/4][64] float4 slots, lane-linear (conflict-free b128).
 template <int CO, int CI, bool FASTG>
-__global__ __launch_bounds__(RT, (CO > 8 ? 3 : 4)) void tail_bwd_lc_kernel(const void* __restrict__ dout, const void* __restrict__ h,
+__global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restrict__ dout, const void* __restrict__ h,
                                                              const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              void* __restrict__ dh, void* __restrict__ dxp, float* __restrict__ partials,
                                                              int rows, int bf, int dout_bf, float p_drop, uint64_t seed,
                                                              const void* __restrict__ dx_add) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int n = 64 * CO, k_in = 64 * CI;
+    constexpr int n = 64 * CO, k_in = 64 * CI, Q = CO / 4;
+    static_assert(CO % 4 == 0, "lane span must be whole float4s");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_g = blockIdx.x * RW + wave;
     const int nwaves = gridDim.x * RW;
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    float acc[3][CO];
+    float4* accw = reinterpret_cast<float4*>(lds) + (size_t)wave * 3 * Q * 64 + lane;  // slot (p, q) at accw[(p*Q+q)*64]
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int c = 0; c < CO; ++c) acc[p][c] = 0.0f;
+    for (int i = 0; i < 3 * Q; ++i) accw[i * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int row = wave_g; row < rows; row += nwaves) {
         const float mean = mean_i[row], rstd = rstd_i[row];
         const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
-        // register diet (this kernel is occupancy bound): gamma/beta are re-read per row (L1 hits) and xhat is recomputed
-        // from h in the second pass instead of being kept
-        float hv[CO], dv[CO], dxh[CO], g[CO], b[CO];
+        float hv[CO], dv[CO], dxh[CO];
         ld_span<CO>(h, (size_t)row * n + lane * CO, bf, hv);
         ld_span<CO>(dout, (size_t)row * n + lane * CO, dout_bf, dv);
-        ld_span<CO>(gamma, (size_t)lane * CO, 0, g);
-        ld_span<CO>(beta, (size_t)lane * CO, 0, b);
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int c = 0; c < CO; ++c) {
-            if (p_drop > 0.0f) dv[c] *= dropout_scale(rkey, (unsigned)(lane * CO + c), p_drop, inv_keep);
-            const float xhat = (hv[c] - mean) * rstd;
-            float dgel, unused;
-            if (FASTG) gelu_fast(xhat * g[c] + b[c], unused, dgel);
-            else dgel = gelu_erf_grad(xhat * g[c] + b[c]);
-            const float dln = dv[c] * dgel;
-            acc[0][c] += dln * xhat;
-            acc[1][c] += dln;
-            const float t = dln * g[c];
-            dxh[c] = t;
-            s1 += t;
-            s2 += t * xhat;
+        for (int q = 0; q < Q; ++q) {
+            float g[4], b[4], a0[4], a1[4];
+            ld_span<4>(gamma, (size_t)lane * CO + 4 * q, 0, g);
+            ld_span<4>(beta, (size_t)lane * CO + 4 * q, 0, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * q + e;
+                if (p_drop > 0.0f) dv[c] *= dropout_scale(rkey, (unsigned)(lane * CO + c), p_drop, inv_keep);
+                const float xhat = (hv[c] - mean) * rstd;
+                float dgel, unused;
+                if (FASTG) gelu_fast(xhat * g[e] + b[e], unused, dgel);
+                else dgel = gelu_erf_grad(xhat * g[e] + b[e]);
+                const float dln = dv[c] * dgel;
+                a0[e] = dln * xhat;
+                a1[e] = dln;
+                const float t = dln * g[e];
+                dxh[c] = t;
+                s1 += t;
+                s2 += t * xhat;
+            }
+            float4 v0 = accw[(0 * Q + q) * 64], v1 = accw[(1 * Q + q) * 64];
+            v0.x += a0[0]; v0.y += a0[1]; v0.z += a0[2]; v0.w += a0[3];
+            v1.x += a1[0]; v1.y += a1[1]; v1.z += a1[2]; v1.w += a1[3];
+            accw[(0 * Q + q) * 64] = v0;
+            accw[(1 * Q + q) * 64] = v1;
+            __builtin_amdgcn_sched_barrier(0);  // keep the chunks sequential: interleaving them only adds live registers
         }
         const float m1 = wave_sum(s1) / (float)n, m2 = wave_sum(s2) / (float)n;
         float o[CO];
 #pragma unroll
-        for (int c = 0; c < CO; ++c) {
-            o[c] = rstd * (dxh[c] - m1 - (hv[c] - mean) * rstd * m2);
-            acc[2][c] += o[c];
+        for (int q = 0; q < Q; ++q) {
+            float4 v2 = accw[(2 * Q + q) * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * q + e;
+                o[c] = rstd * (dxh[c] - m1 - (hv[c] - mean) * rstd * m2);
+            }
+            v2.x += o[4 * q]; v2.y += o[4 * q + 1]; v2.z += o[4 * q + 2]; v2.w += o[4 * q + 3];
+            accw[(2 * Q + q) * 64] = v2;
         }
         st_span<CO>(dh, (size_t)row * n + lane * CO, bf, o);
         // transposed pooling, lane local: input j receives dout[c] / width(c) from every window that covers it
@@ -673,21 +699,18 @@ __global__ __launch_bounds__(RT, (CO > 8 ? 3 : 4)) void tail_bwd_lc_kernel(const
         }
         st_span<CI>(dxp, (size_t)row * k_in + lane * CI, bf, dx);
     }
-    // fold the 4 waves' column partials through LDS in wave order, one slab per workgroup
-    for (int w = 0; w < RW; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int c = 0; c < CO; ++c) {
-                    float* qd = lds + p * n + lane * CO + c;
-                    *qd = (w == 0 ? 0.0f : *qd) + acc[p][c];
-                }
-        }
-        __syncthreads();
-    }
+    __syncthreads();
+    // sum the 4 waves' slots in wave order, one slab per workgroup: slab[p*n + col], col = lane*CO + 4q + e
     float* slab = partials + (size_t)blockIdx.x * 3 * n;
-    for (int c = threadIdx.x; c < 3 * n; c += blockDim.x) slab[c] = lds[c];
+    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) {
+        const int p = i / n, col = i - p * n;
+        const int l = col / CO, r = col - l * CO;
+        const int off = (((p * Q + (r >> 2)) * 64 + l) << 2) + (r & 3);
+        float v = lds[off];
+#pragma unroll
+        for (int w = 1; w < RW; ++w) v += lds[w * 3 * n + off];
+        slab[i] = v;
+    }
 }
 
 #define TAIL_DISPATCH(cfg, fast, KERNEL, grid, lds_bytes, st, ...)                                              \
@@ -792,10 +815,10 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
 #define LC_BWD(CO, CI)                                                                                                        \
         if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
             hipStream_t lst = static_cast<hipStream_t>(stream);                                                               \
-            if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true>), dim3(lwgs), dim3(RT), (size_t)3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add); \
-            else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false>), dim3(lwgs), dim3(RT), (size_t)3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add);    \
+            if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add); \
+            else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add);    \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc)");                                                                     \
-            hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, 32)), dim3(256), 0, lst, partials, dgamma, dbeta, dbias, lwgs, 3, n); \
+            hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, lst, partials, dgamma, dbeta, dbias, lwgs, 3, n); \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc fold)");                                                                \
             return 0;                                                                                                         \
         }
@@ -810,7 +833,7 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
     TAIL_DISPATCH(cfg, dtype == SPV_BF16, tail_bwd_kernel, dim3(wgs), lds, st, dout, h, mean, rstd, gamma, beta, dh,
                  dx_pool, partials, rows, n, k_in, dtype == SPV_BF16, dout_dtype == SPV_BF16, p_drop, seed, pm, dx_add);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd");
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, 32)), dim3(256), 0, st, partials, dgamma, dbeta, dbias, wgs, 3, n);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, wgs, 3, n);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(fold)");
     return 0;
 }
@@ -842,7 +865,7 @@ extern "C" int spv_add_layernorm_bwd(const void* dout, const void* a, const void
     ROW_DISPATCH(cfg, addln_bwd_kernel, dim3(wgs), (size_t)2 * n * sizeof(float), st, dout, a, b, mean, rstd, gamma, din,
                  partials, rows, n, mode, dtype == SPV_BF16);
     SPV_LAUNCH_CHECK("spv_add_layernorm_bwd");
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(2 * n, 32)), dim3(256), 0, st, partials, dgamma, dbeta, (float*)nullptr, wgs, 2, n);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(2 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, (float*)nullptr, wgs, 2, n);
     SPV_LAUNCH_CHECK("spv_add_layernorm_bwd(fold)");
     return 0;
 }

@@ -6,6 +6,7 @@ on a HIP device: a CPU tensor raises (there is deliberately no CPU / eager-PyTor
 """
 from __future__ import annotations
 
+import os
 import warnings
 import weakref
 
@@ -212,6 +213,26 @@ def _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, 
                  _p(workspace), _stream())
 
 
+_SIDE_STREAM = os.environ.get("SPV_SIDE_STREAM", "1") != "0"
+_side_streams = {}
+_side_keep = []  # tensors a side-stream kernel still reads/writes: kept alive until the join
+
+
+def _side_stream(dev):
+    s = _side_streams.get(dev)
+    if s is None:
+        s = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def join_side_stream():
+    """Make the current stream wait for everything launched on the side stream (no-op when nothing is pending)."""
+    if _side_keep:
+        dev = _side_keep[0][0].device
+        torch.cuda.current_stream().wait_stream(_side_streams[dev])
+        _side_keep.clear()
+
+
 def _weight_grad(dh, x, rows, n, k, sink=None):
     """dW[n,k] = dh[rows,n]^T . x[rows,k], split-K over rows.  bf16: TN kernel straight from the row-major activations
     (transposing LDS reads); fp32 (parity path): NT kernel over explicit transposes."""
@@ -220,15 +241,30 @@ def _weight_grad(dh, x, rows, n, k, sink=None):
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
     # ~2 workgroups per CU: measured optimum on the 768 x 512 x 33280 weight gradient (21 splits: 51 us; 12: 69; 42: 56; 64: 64)
     splits = max(1, min(512 // tiles, (rows + 511) // 512))
-    ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev) if splits > 1 else None
+    ws = None
     if dh.dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0:
         def launch():
+            nonlocal ws
+            if ws is None and splits > 1:
+                ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev)
             _native.call("spv_gemm_tn", _p(dh), _p(x), _p(dw), n, k, rows, n, k, k, F32, 0, splits, _p(ws), _stream())
         if _timer is not None:
             _timer.bracket("gemm", (n, k, rows, BF16), launch)
+        elif _SIDE_STREAM and 2.0 * rows * n * k >= 1e11:
+            # a big weight gradient (the MHPermutMix 8192 -> 512 linear: 279 GFLOP) has no consumer inside the backward
+            # chain: run it on a second HIP stream so that it fills the ramp/tail gaps of the data-gradient GEMM and
+            # overlaps the HBM-bound inverse gather on the main stream (10.57 -> 10.38 ms/step).  Not worth it for the
+            # 26-GFLOP layer GEMMs (3.32 -> 3.42 ms/step: the fork/join costs more than the overlap gains).
+            # join_side_stream() (end of the calling autograd node) orders everything after it again.
+            side = _side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                launch()  # allocates its split-K workspace from the side stream's pool
+            _side_keep.append((dh, x, ws, dw))
         else:
             launch()
         return dw
+    ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev) if splits > 1 else None
     ld = (rows + 7) // 8 * 8
     dht = torch.empty((n, ld), dtype=dh.dtype, device=dev)
     xt = torch.empty((k, ld), dtype=x.dtype, device=dev)
@@ -309,11 +345,11 @@ def _sl_backward(dout2, saved, need_dx=True, dx_add=None):
     _native.call("spv_spectre_tail_bwd", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
                  _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
                  _p(dx_add) if need_dx else 0, _stream())
+    dw = _weight_grad(dh, x2, rows, n, k, s_w)  # side stream: overlaps the data gradient below
     if need_dx:
         _gemm(dh, wt, None, dx, rows, k, n, n, wt.shape[1], k, accumulate=1)
     else:
         dx = None
-    dw = _weight_grad(dh, x2, rows, n, k, s_w)
     return dx, dw, dbias, dgamma, dbeta
 
 
@@ -336,6 +372,7 @@ class SpectreLinearFn(torch.autograd.Function):
         saved = ctx.saved
         rows, n = saved[8], saved[9]
         dx, dw, dbias, dgamma, dbeta = _sl_backward(dout.reshape(rows, n), saved, ctx.needs_input_grad[0])
+        join_side_stream()
         return (dx.reshape(ctx.shape) if dx is not None else None), dw, dbias, dgamma, dbeta, None, None
 
 
@@ -679,17 +716,18 @@ class LinearFn(torch.autograd.Function):
             dy2 = _raw_cast(dy2, x2.dtype)
         elif not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        dw = _weight_grad(dy2, x2, rows, n, k, ctx.sinks[0])
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
             _gemm(dy2, ctx.wt, None, dx, rows, k, n, n, ctx.wt.shape[1], k)
             dx = dx.reshape(shape)
-        dw = _weight_grad(dy2, x2, rows, n, k, ctx.sinks[0])
         db = None
         if has_bias:
             db = _grad_buf(ctx.sinks[1], (n,), x2.device)
             part = torch.empty((min(rows, 512) * n,), dtype=torch.float32, device=x2.device)
             _native.call("spv_colsum", _p(dy2), _p(db), _p(part), rows, n, _dt(dy2), _stream())
+        join_side_stream()
         return dx, dw, db, None
 
 
@@ -774,6 +812,7 @@ class FFResidualFn(torch.autograd.Function):
         ds, dn2w, dn2b = _addln_backward(dout.reshape(rows, n), sn)      # d(x1 + f3)
         df1, dw3, db3, dg3, dbe3 = _sl_backward(ds, s3, True)
         dx1, dw1, db1, dg1, dbe1 = _sl_backward(df1, s1, True, dx_add=ds)  # + the residual path, folded in
+        join_side_stream()
         return dx1.reshape(ctx.shape), dw1, db1, dg1, dbe1, dw3, db3, dg3, dbe3, dn2w, dn2b, None
 
 
@@ -864,6 +903,7 @@ class PermutMixFn(torch.autograd.Function):
         fast = pw > 0
         _native.call("spv_spectre_tail_bwd", _p(d2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), 0 if fast else _p(dg),
                      _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(d2), 0.0, 0, 0, st)
+        dw = _weight_grad(dh, g, rows, n, k, s_w)  # side stream: overlaps the data gradient and the inverse gather
         if fast:
             def launch():
                 _native.call("spv_gemm_nt_pool_bwd", _p(dh), _p(wt), _p(dg), _p(d2), pw, rows, k, n, n, wt.shape[1], k, _dt(dh),
@@ -874,7 +914,7 @@ class PermutMixFn(torch.autograd.Function):
                 launch()
         else:
             _gemm(dh, wt, None, dg, rows, k, n, n, wt.shape[1], k, accumulate=1)
-        dw = _weight_grad(dh, g, rows, n, k, s_w)
         dx = torch.empty((B, d), dtype=g.dtype, device=dev)
         _native.call("spv_permut_gather_bwd", _p(dg), _p(idx), _p(dx), B, heads, d, _dt(dg), st)
+        join_side_stream()
         return dx.reshape(xshape), None, None, dw, dbias, dgamma, dbeta
