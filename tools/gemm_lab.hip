@@ -1,0 +1,393 @@
+// gemm_lab.hip -- ablation timings of the NT GEMM tile loop at the layer shapes (development tool, not shipped).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_lab.hip -o tools/_build/gemm_lab && tools/_build/gemm_lab
+// Re-uses the product kernels' building blocks by including the translation unit; adds copies of the tile loop with
+// parts switched off (results are then wrong on purpose) to see which resource the loop is waiting for.
+#include "../vit-spectre-experiments_amd/csrc/spv_gemm.hip"
+#include "../vit-spectre-experiments_amd/csrc/spv_misc.hip"
+
+#include <math.h>
+#include <string.h>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+// ABL bits: 1 = no C store, 2 = B staged once, 4 = A staged once, 8 = no MFMA
+template <int WMB, int NST, int ABL>
+__global__ __launch_bounds__(256) void lab_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C,
+                                                  int M, int N, int K, int tiles_n, int tiles_mn) {
+    constexpr int WBM = 64 * WMB, KB = 64, KE = KB / 2;
+    constexpr int STAGE = (WBM + BN) * KB;
+    constexpr int IPA = WBM / 16 / 4, IPB = BN / 16 / 4;
+    constexpr int SM = NST * STAGE > 36864 ? NST * STAGE : 36864;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, tiles_mn);
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * WBM, n0 = tn * BN;
+    const bf16_t* asrc[IPA];
+    const bf16_t* bsrc[IPB];
+#pragma unroll
+    for (int t = 0; t < IPA; ++t) {
+        const int R = 16 * (wave * IPA + t) + (lane >> 2);
+        const int c = (lane & 3) ^ ((R >> 2) & 3);
+        asrc[t] = A + (size_t)min(m0 + R, M - 1) * K + c * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < IPB; ++t) {
+        const int R = 16 * (wave * IPB + t) + (lane >> 2);
+        const int c = (lane & 3) ^ ((R >> 2) & 3);
+        bsrc[t] = B + (size_t)min(n0 + R, N - 1) * K + c * 8;
+    }
+    auto stage = [&](int buf, int k0, bool first) {
+        unsigned char* sa = smem + buf * STAGE + wave * IPA * 1024;
+        unsigned char* sb = smem + buf * STAGE + WBM * KB + wave * IPB * 1024;
+        if (first || !(ABL & 4)) {
+#pragma unroll
+            for (int t = 0; t < IPA; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[t] + k0),
+                                                 (__attribute__((address_space(3))) void*)(sa + t * 1024), 16, 0, 0);
+        }
+        if (first || !(ABL & 2)) {
+#pragma unroll
+            for (int t = 0; t < IPB; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[t] + k0),
+                                                 (__attribute__((address_space(3))) void*)(sb + t * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 acc[WMB][2];
+#pragma unroll
+    for (int i = 0; i < WMB; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 2) & 3;
+    const int fa_off = (wm * 32 * WMB + frow) * KB, fb_off = WBM * KB + (wn * 64 + frow) * KB;
+    const int nk = K / KE;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stage(s, s * KE, true);
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (!(ABL & 16) && t + NST - 1 < nk) stage((buf + NST - 1) % NST, (t + NST - 1) * KE, false);
+        const unsigned char* sa = smem + buf * STAGE + fa_off;
+        const unsigned char* sb = smem + buf * STAGE + fb_off;
+        if (ABL & 16) {
+            // all fragment reads of the stage first, then the MFMAs with the next stage's DMA pieces spread between them
+            auto body = [&](auto more_tag) {
+                constexpr bool MORE = decltype(more_tag)::value;
+                bf16x8 a[2][WMB], b[2][2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int ch = ((ks * 2 + fh) ^ swz) * 16;
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) b[ks][f] = *reinterpret_cast<const bf16x8*>(sb + f * 32 * KB + ch);
+#pragma unroll
+                    for (int f = 0; f < WMB; ++f) a[ks][f] = *reinterpret_cast<const bf16x8*>(sa + f * 32 * KB + ch);
+                }
+                const int nb = (buf + NST - 1) % NST, k0 = (t + NST - 1) * KE;
+                unsigned char* da = smem + nb * STAGE + wave * IPA * 1024;
+                unsigned char* db = smem + nb * STAGE + WBM * KB + wave * IPB * 1024;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < WMB; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+                            constexpr int EVERY = (4 * WMB) / (IPA + IPB);
+                            const int m = (ks * WMB + i) * 2 + j;  // MFMA index 0 .. 4*WMB-1
+                            const int piece = m / EVERY;
+                            if (MORE && (m % EVERY) == EVERY - 1 && piece < IPA + IPB) {
+                                if (piece < IPA)
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[piece < IPA ? piece : 0] + k0),
+                                                                     (__attribute__((address_space(3))) void*)(da + piece * 1024), 16, 0, 0);
+                                else
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[piece >= IPA ? piece - IPA : 0] + k0),
+                                                                     (__attribute__((address_space(3))) void*)(db + (piece - IPA) * 1024), 16, 0, 0);
+                            }
+                        }
+            };
+            if (t + NST - 1 < nk) body(std::true_type{});
+            else body(std::false_type{});
+            buf = (buf + 1 == NST) ? 0 : buf + 1;
+            continue;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((ks * 2 + fh) ^ swz) * 16;
+            bf16x8 a[WMB], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) b[f] = *reinterpret_cast<const bf16x8*>(sb + f * 32 * KB + ch);
+#pragma unroll
+            for (int f = 0; f < WMB; ++f) a[f] = *reinterpret_cast<const bf16x8*>(sa + f * 32 * KB + ch);
+            if (!(ABL & 8)) {
+#pragma unroll
+                for (int i = 0; i < WMB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < WMB; ++i) acc[i][0][0] += (float)a[i][0] + (float)b[i & 1][1];
+            }
+        }
+        buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+    if (ABL & 1) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < WMB; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 1234.5678f) C[0] = 1;
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < WMB / 2; ++h)
+        store_acc_tile<bf16_t>(acc + 2 * h, smem, nullptr, C, nullptr, M, N, N, 0, m0, n0, 0, 0, 0, 0, nullptr, nullptr, 0, 0,
+                               wm * 32 * WMB + 64 * h);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// full-N tile: one 512-thread workgroup per 128 rows x ALL N columns (N = 4 * NBLK * 32), 8 waves as 2 (M) x 4 (N),
+// wave tile 64 x (NBLK*32).  A is read once from HBM, B (the weight) streams from L2 once per workgroup.  K staged 16
+// elements (32-byte rows) per stage, NST-deep LDS ring filled by LDS-DMA with counted vmcnt, one barrier per stage.
+// Accumulators hold C^T blocks (operands swapped) so that a lane owns 4 consecutive columns of one row: 8-byte stores,
+// no LDS epilogue.
+template <int NBLK, int NST, int ABL>
+__global__ __launch_bounds__(512) void fulln_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C,
+                                                    int M, int K) {
+    constexpr int N = 4 * NBLK * 32, NW = NBLK * 32;
+    constexpr int ROWS = 128 + N;           // tile rows per stage (A then B), 32 B each
+    constexpr int STAGE = ROWS * 32;
+    constexpr int NI = ROWS / 32;           // DMA wave-instructions per stage
+    constexpr int LPW_HI = (NI + 7) / 8, REM = NI % 8;  // waves < REM issue LPW_HI, the others LPW_HI - 1 (REM == 0: all LPW_HI)
+    constexpr int D = NST - 1;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int m0 = blockIdx.x * 128;
+    // per-lane source pointers for this wave's DMA instructions
+    const bf16_t* src[LPW_HI];
+#pragma unroll
+    for (int t = 0; t < LPW_HI; ++t) {
+        const int i = wave + 8 * t;                 // instruction index within the stage
+        const int R = 32 * i + (lane >> 1);         // tile row (A rows first)
+        const int c = (lane & 1) ^ ((R >> 3) & 1);  // logical 16-byte chunk stored at this lane's LDS slot
+        if (i < NI) src[t] = R < 128 ? A + (size_t)min(m0 + R, M - 1) * K + c * 8 : B + (size_t)(R - 128) * K + c * 8;
+        else src[t] = A;
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int t = 0; t < LPW_HI; ++t) {
+            const int i = wave + 8 * t;
+            if (i < NI)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + k0),
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * STAGE + i * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][NBLK];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int frow = lane & 31, fh = lane >> 5;
+    const int pch = (fh ^ ((frow >> 3) & 1)) * 16;  // 32-row block offsets do not change the swizzle bit
+    const int fa_off = (wm * 64 + frow) * 32 + pch, fb_off = (128 + wn * NW + frow) * 32 + pch;
+    const int nk = K / 16;
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nk) stage(s, s * 16);
+    int buf = 0;
+    const bool hi = REM == 0 || wave < REM;
+    for (int t = 0; t < nk; ++t) {
+        if (t + D - 1 < nk) {
+            if (hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * LPW_HI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * (LPW_HI - 1)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (t + D < nk && !(ABL & 6)) stage((buf + D) % NST, (t + D) * 16);
+        const unsigned char* sa = smem + buf * STAGE + fa_off;
+        const unsigned char* sb = smem + buf * STAGE + fb_off;
+        bf16x8 a[2], b[NBLK];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) a[f] = *reinterpret_cast<const bf16x8*>(sa + f * 32 * 32);
+#pragma unroll
+        for (int f = 0; f < NBLK; ++f) b[f] = *reinterpret_cast<const bf16x8*>(sb + f * 32 * 32);
+        if (!(ABL & 8)) {
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j) acc[j & 1][j][0] += (float)a[j & 1][0] + (float)b[j][1];
+        }
+        buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+    if (ABL & 1) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 1234.5678f) C[0] = 1;
+        return;
+    }
+    // C^T blocks: lane -> row m = frow, registers r -> column (r & 3) + 8 (r >> 2) + 4 fh
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + wm * 64 + i * 32 + frow;
+        if (row >= M) continue;
+        bf16_t* cp = C + (size_t)row * N + wn * NW + 4 * fh;
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 o;
+                o.x = (unsigned)f2bf(acc[i][j][4 * q]) | ((unsigned)f2bf(acc[i][j][4 * q + 1]) << 16);
+                o.y = (unsigned)f2bf(acc[i][j][4 * q + 2]) | ((unsigned)f2bf(acc[i][j][4 * q + 3]) << 16);
+                *reinterpret_cast<uint2*>(cp + j * 32 + 8 * q) = o;
+            }
+    }
+}
+
+template <int NBLK, int NST, int ABL>
+float run_fulln(const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int K, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int grid = (M + 127) / 128;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((fulln_kernel<NBLK, NST, ABL>), dim3(grid), dim3(512), 0, 0, A, B, C, M, K);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((fulln_kernel<NBLK, NST, ABL>), dim3(grid), dim3(512), 0, 0, A, B, C, M, K);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) printf("HIP error: %s\n", hipGetErrorString(e));
+    return ms * 1e3f / iters;
+}
+
+// reference check of a few rows on the host
+static double check_rows(const std::vector<bf16_t>& hA, const std::vector<bf16_t>& hB, const bf16_t* dC, int M, int N, int K) {
+    auto f = [](bf16_t v) { unsigned u = ((unsigned)v) << 16; float x; memcpy(&x, &u, 4); return x; };
+    const int rows[] = {0, 1, 31, 32, 63, 64, 127, 128, 129, 1000, M - 129, M - 1};
+    std::vector<bf16_t> hc(N);
+    double worst = 0;
+    for (int r : rows) {
+        hipMemcpy(hc.data(), dC + (size_t)r * N, N * 2, hipMemcpyDeviceToHost);
+        for (int n = 0; n < N; ++n) {
+            double s = 0;
+            for (int k = 0; k < K; ++k) s += (double)f(hA[(size_t)r * K + k]) * f(hB[(size_t)n * K + k]);
+            const double d = fabs(s - f(hc[n])) / (fabs(s) + 1.0);
+            if (d > worst) worst = d;
+        }
+    }
+    return worst;
+}
+
+template <int WMB, int NST, int ABL>
+float run(const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, int iters) {
+    const int tiles_n = N / BN, tiles_m = (M + 64 * WMB - 1) / (64 * WMB);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL((lab_kernel<WMB, NST, ABL>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, A, B, C, M, N, K, tiles_n, tiles_m * tiles_n);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL((lab_kernel<WMB, NST, ABL>), dim3(tiles_m * tiles_n), dim3(256), 0, 0, A, B, C, M, N, K, tiles_n, tiles_m * tiles_n);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f / iters;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 33280, N = argc > 2 ? atoi(argv[2]) : 768, K = argc > 3 ? atoi(argv[3]) : 512;
+    bf16_t *A, *B, *C;
+    hipMalloc(&A, (size_t)M * K * 2);
+    hipMalloc(&B, (size_t)N * K * 2);
+    hipMalloc(&C, (size_t)M * N * 2);
+    std::vector<bf16_t> h((size_t)M * K);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (bf16_t)(0x3c00 + (i * 2654435761u >> 20 & 0x1ff) + ((i & 1) << 15));
+    hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(B, h.data(), (size_t)N * K * 2, hipMemcpyHostToDevice);
+    const double gf = 2.0 * M * N * K * 1e-6;
+    printf("M=%d N=%d K=%d\n", M, N, K);
+    std::vector<bf16_t> hB(h.begin(), h.begin() + (size_t)N * K);
+#define RUNF(NB, S, ABL, label)                                                                   \
+    {                                                                                             \
+        float us = run_fulln<NB, S, ABL>(A, B, C, M, K, 20);                                      \
+        printf("full-N %3d stages %d %-34s %8.2f us  %7.1f TFLOP/s", NB * 128, S, label, us, gf / us); \
+        if (ABL == 0) printf("  max rel err %.2e", check_rows(h, hB, C, M, N, K));                \
+        printf("\n");                                                                             \
+        fflush(stdout);                                                                           \
+    }
+    if (N == 768) {
+        RUNF(6, 5, 0, "full")
+        RUNF(6, 5, 1, "no C store")
+        RUNF(6, 5, 6, "staged once")
+        RUNF(6, 5, 7, "staged once, no C store")
+        RUNF(6, 5, 8, "no MFMA")
+        RUNF(6, 4, 0, "full")
+        RUNF(6, 3, 0, "full")
+    }
+    if (N == 512) {
+        RUNF(4, 6, 0, "full")
+        RUNF(4, 6, 1, "no C store")
+        RUNF(4, 6, 6, "staged once")
+        RUNF(4, 6, 7, "staged once, no C store")
+        RUNF(4, 4, 0, "full")
+        RUNF(4, 7, 0, "full")
+    }
+#define RUN(W, S, ABL, label)                                                                     \
+    {                                                                                             \
+        float us = run<W, S, ABL>(A, B, C, M, N, K, 20);                                          \
+        printf("tile %3dx128 stages %d %-34s %8.2f us  %7.1f TFLOP/s\n", 64 * W, S, label, us, gf / us); \
+        fflush(stdout);                                                                           \
+    }
+    RUN(2, 2, 0, "full")
+    RUN(2, 2, 1, "no C store")
+    RUN(2, 2, 2, "B staged once")
+    RUN(2, 2, 4, "A staged once")
+    RUN(2, 2, 6, "A and B staged once")
+    RUN(2, 2, 7, "A, B once, no C store")
+    RUN(2, 2, 8, "no MFMA")
+    RUN(2, 2, 9, "no MFMA, no C store")
+    RUN(2, 3, 0, "full")
+    RUN(2, 3, 1, "no C store")
+    RUN(2, 2, 16, "interleaved glds")
+    RUN(2, 2, 17, "interleaved glds, no C store")
+    RUN(2, 3, 16, "interleaved glds")
+    RUN(2, 3, 17, "interleaved glds, no C store")
+    RUN(4, 2, 16, "interleaved glds")
+    RUN(4, 2, 17, "interleaved glds, no C store")
+    RUN(4, 2, 0, "full")
+    RUN(4, 2, 1, "no C store")
+    RUN(4, 2, 6, "A and B staged once")
+    RUN(4, 2, 7, "A, B once, no C store")
+    RUN(4, 3, 0, "full")
+    RUN(4, 3, 1, "no C store")
+    return 0;
+}

@@ -76,13 +76,43 @@ __global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ x, con
 }
 
 // column sums: block b sums rows b, b+G, ... for all columns into partials[b][n]; second kernel folds.
-template <typename T>
+// column sums, stage 1: grid (column blocks, row slabs).  A 256-thread workgroup is TX column threads (VEC consecutive
+// columns each: 16-/8-byte loads) x TY = 256/TX row threads; slab y sums rows y*TY + ty, + gridDim.y*TY, ...; the TY
+// partial rows meet in LDS in a fixed order; one fp32 row of partials per slab.  Wide-and-short inputs (512 x 33280,
+// the position-embedding gradient) get many column blocks, tall-and-narrow ones (33280 x 512) many slabs.
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ partials, int rows,
-                                                             int n) {
-    for (int c = threadIdx.x; c < n; c += blockDim.x) {
-        float s = 0.0f;
-        for (int r = blockIdx.x; r < rows; r += gridDim.x) s += io<T>::ld(x + (size_t)r * n + c);
-        partials[(size_t)blockIdx.x * n + c] = s;
+                                                             int n, int tx_log2) {
+    __shared__ float red[256 * VEC];
+    const int TX = 1 << tx_log2, TY = 256 >> tx_log2;
+    const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> tx_log2;
+    const int c0 = (blockIdx.x * TX + tx) * VEC;
+    float s[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) s[k] = 0.0f;
+    if (c0 < n) {
+        const int step = gridDim.y * TY;
+        for (int r = blockIdx.y * TY + ty; r < rows; r += step) {
+            if constexpr (VEC == 4) {
+                float v[4];
+                io<T>::ld4(x + (size_t)r * n + c0, v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += v[k];
+            } else {
+                s[0] += io<T>::ld(x + (size_t)r * n + c0);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) red[(ty * TX + tx) * VEC + k] = s[k];
+    __syncthreads();
+    if (ty == 0 && c0 < n) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            float t = s[k];
+            for (int q = 1; q < TY; ++q) t += red[(q * TX + tx) * VEC + k];
+            if (c0 + k < n) partials[(size_t)blockIdx.y * n + c0 + k] = t;
+        }
     }
 }
 __global__ __launch_bounds__(256) void colsum_fold_kernel(const float* __restrict__ partials, float* __restrict__ out, int parts,
@@ -182,9 +212,21 @@ extern "C" int spv_axpby(const void* x, const void* y, void* out, float a, float
 extern "C" int spv_colsum(const void* x, float* out, float* partials, int rows, int n, int dtype, void* stream) {
     SPV_CHECK(rows > 0 && n > 0, "spv_colsum: empty");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int parts = std::min(rows, 512);
-    DISPATCH_T(dtype, "spv_colsum",
-               hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3(parts), dim3(256), 0, st, (const T*)x, partials, rows, n));
+    const int vec = (n % 4 == 0 && ((uintptr_t)x & 15) == 0) ? 4 : 1;
+    const int cthreads = cdiv(n, vec);
+    int tx_log2 = 5;  // at least 32 column threads
+    while (tx_log2 < 8 && (1 << tx_log2) < cthreads) ++tx_log2;
+    const int ty = 256 >> tx_log2;
+    const int gx = cdiv(cthreads, 1 << tx_log2);
+    // ~1024 workgroups in all, at most 512 slabs (the caller's partial buffer holds min(rows, 512) rows of n floats)
+    const int parts = std::max(1, std::min(std::min(cdiv(rows, ty), 512), std::max(1, 1024 / gx)));
+    if (vec == 4) {
+        DISPATCH_T(dtype, "spv_colsum",
+                   hipLaunchKernelGGL((colsum_partial_kernel<T, 4>), dim3(gx, parts), dim3(256), 0, st, (const T*)x, partials, rows, n, tx_log2));
+    } else {
+        DISPATCH_T(dtype, "spv_colsum",
+                   hipLaunchKernelGGL((colsum_partial_kernel<T, 1>), dim3(gx, parts), dim3(256), 0, st, (const T*)x, partials, rows, n, tx_log2));
+    }
     SPV_LAUNCH_CHECK("spv_colsum");
     hipLaunchKernelGGL(colsum_fold_kernel, dim3(cdiv(n, 32)), dim3(256), 0, st, partials, out, parts, n);
     SPV_LAUNCH_CHECK("spv_colsum(fold)");

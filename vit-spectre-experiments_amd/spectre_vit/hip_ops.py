@@ -608,13 +608,14 @@ class PatchEmbedFn(torch.autograd.Function):
         _native.call("spv_gemm_nt_grouped_rows", _p(patches), _p(wc), 0, _p(posbias), _p(tokens), B * Np, E, K, K, K, E,
                      _DT[dtype], _DT[dtype], Np, T, 1, st)
         _native.call("spv_embed_cls_rows", _p(cls), _p(pos), _p(tokens), B, T, E, _DT[dtype], st)
-        ctx.save_for_backward(img)
+        # bf16: the backward's TN weight-gradient GEMM reads the patch matrix as it lies here (3 MB), so keep it
+        ctx.save_for_backward(img, patches if dtype == torch.bfloat16 else None)
         ctx.meta = (B, C, H, W, patch, E, K, Np, T, dtype, cls.shape, pos.shape)
         return tokens
 
     @staticmethod
     def backward(ctx, dtok):
-        (img,) = ctx.saved_tensors
+        img, patches = ctx.saved_tensors
         B, C, H, W, patch, E, K, Np, T, dtype, cls_shape, pos_shape = ctx.meta
         dev = dtok.device
         st = _stream()
@@ -625,6 +626,14 @@ class PatchEmbedFn(torch.autograd.Function):
         dbias = torch.empty((E,), dtype=torch.float32, device=dev)
         _native.call("spv_colsum", _p(dpos[1:]), _p(dbias), _p(part), T - 1, E, F32, st)
         dcls = dpos[0].clone().reshape(cls_shape)
+        if patches is not None and dtok.dtype == torch.bfloat16:
+            # dW = dtok^T . P over all B*T token rows, with P the patch matrix widened by a zero row per image (the CLS
+            # row): the TN kernel then takes dtok as it lies in memory -- no transposed copies of a 34 MB tensor
+            pfull = torch.zeros((B, T, K), dtype=dtok.dtype, device=dev)
+            pfull[:, 1:, :] = patches.view(B, Np, K)
+            dwf = _weight_grad(dtok.view(B * T, E), pfull.view(B * T, K), B * T, E, K)
+            join_side_stream()
+            return None, dwf, dbias, dcls, dpos.reshape(pos_shape), None, None
         rows = B * Np
         ld = (rows + 7) // 8 * 8
         dyt = torch.empty((E, ld), dtype=dtok.dtype, device=dev)
