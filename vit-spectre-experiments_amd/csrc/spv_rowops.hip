@@ -447,30 +447,49 @@ __global__ __launch_bounds__(RT) void addln_bwd_kernel(const void* __restrict__ 
         for (int i = 0; i < MAXI; ++i)
 #pragma unroll
             for (int k = 0; k < VEC; ++k) acc[p][i][k] = 0.0f;
+    // the rows a wave owns are a serial chain (load -> two wave reductions -> store) with loop-carried column sums, so
+    // the next row's loads are issued before the current row is reduced: two rows in flight per wave
+    float av[MAXI][VEC], dv[MAXI][VEC], mean = 0.0f, rstd = 0.0f;
+    auto fetch = [&](int row, float (&fa)[MAXI][VEC], float (&fd)[MAXI][VEC], float& fm, float& fr) {
+        fm = mean_i[row];
+        fr = rstd_i[row];
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int e0 = (i * 64 + lane) * VEC;
+            if (e0 < n) {
+                ldv<VEC>(a, (size_t)row * n + e0, bf, fa[i]);
+                if (mode == 1) {
+                    float bv[VEC];
+                    ldv<VEC>(b, (size_t)row * n + e0, bf, bv);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) fa[i][k] += bv[k];
+                }
+                ldv<VEC>(dout, (size_t)row * n + e0, bf, fd[i]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { fa[i][k] = 0.0f; fd[i][k] = 0.0f; }
+            }
+        }
+    };
+    if (wave_g < rows) fetch(wave_g, av, dv, mean, rstd);
     for (int row = wave_g; row < rows; row += nwaves) {
-        const float mean = mean_i[row], rstd = rstd_i[row];
+        float nav[MAXI][VEC], ndv[MAXI][VEC], nmean = 0.0f, nrstd = 0.0f;
+        const int nrow = row + nwaves;
+        if (nrow < rows) fetch(nrow, nav, ndv, nmean, nrstd);
         float xh[MAXI][VEC], dxh[MAXI][VEC];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int i = 0; i < MAXI; ++i) {
             const int e0 = (i * 64 + lane) * VEC;
             if (e0 < n) {
-                float av[VEC], dv[VEC], g[VEC];
-                ldv<VEC>(a, (size_t)row * n + e0, bf, av);
-                if (mode == 1) {
-                    float bv[VEC];
-                    ldv<VEC>(b, (size_t)row * n + e0, bf, bv);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) av[k] += bv[k];
-                }
-                ldv<VEC>(dout, (size_t)row * n + e0, bf, dv);
+                float g[VEC];
                 ldv<VEC>(gamma, e0, 0, g);
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
-                    float xhat = (av[k] - mean) * rstd;
-                    acc[0][i][k] += dv[k] * xhat;
-                    acc[1][i][k] += dv[k];
-                    float t = dv[k] * g[k];
+                    float xhat = (av[i][k] - mean) * rstd;
+                    acc[0][i][k] += dv[i][k] * xhat;
+                    acc[1][i][k] += dv[i][k];
+                    float t = dv[i][k] * g[k];
                     xh[i][k] = xhat;
                     dxh[i][k] = t;
                     s1 += t;
@@ -491,6 +510,12 @@ __global__ __launch_bounds__(RT) void addln_bwd_kernel(const void* __restrict__ 
             for (int k = 0; k < VEC; ++k) o[k] = rstd * (dxh[i][k] - m1 - xh[i][k] * m2);
             stv<VEC>(din, (size_t)row * n + e0, bf, o);
         }
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { av[i][k] = nav[i][k]; dv[i][k] = ndv[i][k]; }
+        mean = nmean;
+        rstd = nrstd;
     }
     write_partials<VEC, MAXI, 2>(acc, lds, partials + (size_t)blockIdx.x * 2 * n, n, lane, wave);
 }
