@@ -159,6 +159,11 @@ int spv_haar_dwt(const void* x, void* y, int batch, int tokens, int dim, int axi
  *                       mask that the backward regenerates (same call on the gradient). */
 int spv_patchify(const float* img, void* out, int batch, int chans, int height, int width, int patch, int ld,
                  int transposed, int out_dtype, void* stream);
+/* spv_patchify_u8: the same rows from the data loader's uint8 HWC batch [B,H,W,C], normalised on the fly as
+ * ToTensor + Normalize(mean, std) do on the host (spectre_vit/repl/train.py:102-112):
+ * (pixel / 255 - mean[c]) * inv_std[c]. */
+int spv_patchify_u8(const unsigned char* img_hwc, const float* mean, const float* inv_std, void* out, int batch, int chans,
+                    int height, int width, int patch, int ld, int transposed, int out_dtype, void* stream);
 int spv_embed_posbias(const float* pos, const float* bias, float* out, int patches, int embed, void* stream);
 int spv_embed_cls_rows(const float* cls, const float* pos, void* tokens, int batch, int tokens_per_image, int embed,
                        int dtype, void* stream);

@@ -332,6 +332,14 @@ def transformer_layer_bwd(dout, p, num_heads, cache, batch_first=False):
 # --------------------------------------------------------------------------------------
 # patch embeddings
 # --------------------------------------------------------------------------------------
+def normalize_u8(img_u8_hwc, mean, std):
+    """The loader's per-image transform restated for a whole batch: ToTensor (uint8 HWC -> float CHW / 255) followed by
+    Normalize(mean, std) per channel -- spectre_vit/repl/train.py:102-112.  (B,H,W,C) uint8 -> (B,C,H,W) float64."""
+    x = img_u8_hwc.astype(np.float64) / 255.0
+    x = (x - np.asarray(mean, np.float64)) / np.asarray(std, np.float64)
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+
+
 def patchify(img, P):
     """(B,C,H,W) -> (B, N, C, P, P) with n = ih*nW + iw  -- spectre.py:130-133."""
     B, C, H, W = img.shape

@@ -326,6 +326,55 @@ def test_spectral_patch_embed_cifar_shape(ops, dtype):
     check(m.proj.bias.grad, gr["proj_bias"], tol * 3, "dbias")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["spectral", "conv"])
+def test_patch_embed_uint8_input(ops, dtype, kind):
+    """uint8 NHWC batch, /255 + Normalize(mean, std) folded into the patch gather (train.py:102-112)."""
+    from spectre_vit.models.spectre.spectre import SpectralPatchEmbed
+    from spectre_vit.modules.patch_embeddings import PatchEmbedding
+    torch.manual_seed(11)
+    m = (SpectralPatchEmbed if kind == "spectral" else PatchEmbedding)(512, 4, 64, 0.0, 3).to(dev())
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(5, 32, 32, 3), dtype=np.uint8)
+    x8 = torch.from_numpy(img).to(dev())
+    dy = torch.randn(5, 65, 512, device=dev())
+    ref_in = O.normalize_u8(img, ops.CIFAR100_MEAN, ops.CIFAR100_STD)
+
+    def run(inp):
+        m.zero_grad()
+        if dtype == torch.bfloat16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(inp)
+        else:
+            y = m(inp)
+        y.backward(dy.to(y.dtype))
+        return y.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    y8, g8 = run(x8)
+    yf, gf = run(t(ref_in))  # the float NCHW contract on the oracle-normalised image
+    assert y8.dtype == dtype and y8.shape == (5, 65, 512)
+    tol = 2e-6 if dtype == torch.float32 else 1e-2  # fp32: one rounding apart (x * (1/255), * (1/std)); bf16: input rounding
+    check(y8, n64(yf), tol, "tokens")
+    for k in g8:
+        check(g8[k], n64(gf[k]), tol * 4, "grad " + k)
+    # and against the oracle end to end (fp32)
+    if dtype == torch.float32 and kind == "spectral":
+        sd = {k: n64(v) for k, v in m.state_dict().items()}
+        p = dict(freq_weight_h=sd["freq_weight_h"], freq_weight_w=sd["freq_weight_w"], proj_weight=sd["proj.weight"],
+                 proj_bias=sd["proj.bias"], cls_token=sd["cls_token"], position_embeddings=sd["position_embeddings"])
+        ref, _ = O.spectral_patch_embed_fwd(ref_in, p, 4)
+        check(y8, ref, 3e-5, "tokens vs oracle")
+
+
+def test_patch_embed_uint8_needs_matching_channels(ops):
+    from spectre_vit.models.spectre.spectre import SpectralPatchEmbed
+    m = SpectralPatchEmbed(64, 4, 4, 0.0, 1).to(dev())
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 8, 8, 1, dtype=torch.uint8, device=dev()))  # default CIFAR statistics have 3 channels
+    m.pixel_norm = ops.PixelNorm((0.5,), (0.25,))
+    assert m(torch.zeros(2, 8, 8, 1, dtype=torch.uint8, device=dev())).shape == (2, 5, 64)
+
+
 def test_dropout_kernel(ops):
     x = torch.ones(1 << 20, device=dev(), requires_grad=True)
     y = ops.DropoutFn.apply(x, 0.1)

@@ -63,6 +63,19 @@ def test_harness_trains_and_checkpoints(tmp_path, distill):
 
 
 @pytest.mark.gpu
+def test_harness_uint8_input_matches_float_input(tmp_path):
+    """the loader's uint8 batches fed straight to the model give the same training curve as host-normalised
+    float batches (same seeds; the two paths differ by one fp32 rounding in the normalisation)."""
+    from spectre_vit.harness import train
+    cfg = "spectre_vit/configs/spectre_vit_mnist.py"
+    kw = dict(mixer="fft", epochs=2, steps_per_epoch=8, batch_size=64, n_train=512, n_val=128, use_amp=False, log=lambda r: None)
+    _, h_float = train(cfg, out_dir=str(tmp_path / "f"), **kw)
+    _, h_u8 = train(cfg, out_dir=str(tmp_path / "u"), uint8_input=True, **kw)
+    for a, b in zip(h_float, h_u8):
+        assert abs(a["Loss/Train"] - b["Loss/Train"]) < 2e-3 * abs(a["Loss/Train"]), (a, b)
+
+
+@pytest.mark.gpu
 def test_first_steps_loss_curve_vs_oracle():
     """the first optimisation steps on a fixed synthetic batch follow the oracle's loss curve (fp32)."""
     from conftest import load_model_fixture

@@ -96,3 +96,16 @@ def test_product_never_imports_oracle():
         for f in fs:
             if f.endswith((".py", ".hip", ".h")):
                 assert "oracle" not in open(os.path.join(dp, f)).read().replace("oracle/", "").lower() or f == "__init__.py", f
+
+
+def test_oracle_normalize_u8_matches_totensor_normalize():
+    """train.py:102-112: ToTensor (HWC uint8 -> CHW float / 255) then Normalize(mean, std), restated with torch ops."""
+    import numpy as np
+    import torch
+    from oracle import spectre_oracle as O
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(3, 8, 8, 3), dtype=np.uint8)
+    mean, std = (0.5071, 0.4867, 0.4408), (0.2675, 0.2565, 0.2761)
+    x = torch.from_numpy(img).permute(0, 3, 1, 2).double() / 255.0
+    ref = (x - torch.tensor(mean, dtype=torch.float64).view(1, 3, 1, 1)) / torch.tensor(std, dtype=torch.float64).view(1, 3, 1, 1)
+    np.testing.assert_allclose(O.normalize_u8(img, mean, std), ref.numpy(), rtol=0, atol=1e-14)

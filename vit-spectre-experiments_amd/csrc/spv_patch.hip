@@ -36,6 +36,32 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     }
 }
 
+// The same patch rows straight from the loader's uint8 HWC image (spectre_vit/repl/train.py:102-112: ToTensor = /255,
+// then Normalize(mean, std) per channel): out = (img[b][y][x][c] / 255 - mean[c]) * inv_std[c].  One pass instead of
+// host-side float conversion + normalise + NCHW copy + patchify.
+__global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* __restrict__ img, const float* __restrict__ mean,
+                                                          const float* __restrict__ inv_std, void* __restrict__ out, int B, int C,
+                                                          int H, int W, int P, int ld, int transposed, int bf) {
+    const int nH = H / P, nW = W / P, Np = nH * nW, K = C * P * P;
+    const int64_t rows = (int64_t)B * Np;
+    const int64_t total = transposed ? (int64_t)K * ld : rows * ld;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t row;
+        int k;
+        if (transposed) { k = (int)(e / ld); row = e % ld; }
+        else { row = e / ld; k = (int)(e % ld); }
+        float v = 0.0f;
+        if (row < rows && k < K) {
+            const int b = (int)(row / Np), n = (int)(row % Np);
+            const int ih = n / nW, iw = n % nW;
+            const int c = k / (P * P), p = (k / P) % P, q = k % P;
+            const float px = (float)img[(((size_t)b * H + ih * P + p) * W + iw * P + q) * C + c];
+            v = (px * (1.0f / 255.0f) - mean[c]) * inv_std[c];
+        }
+        st_any(out, (size_t)e, bf, v);
+    }
+}
+
 // posbias[t][e] = pos[1 + t][e] + bias[e]
 __global__ __launch_bounds__(256) void posbias_kernel(const float* __restrict__ pos, const float* __restrict__ bias,
                                                       float* __restrict__ out, int Np, int E) {
@@ -139,6 +165,21 @@ extern "C" int spv_patchify(const float* img, void* out, int batch, int chans, i
     hipLaunchKernelGGL(patchify_kernel, dim3(ew_blocks(total)), dim3(256), 0, static_cast<hipStream_t>(stream), img, out, batch,
                        chans, height, width, patch, ld, transposed, out_dtype == SPV_BF16);
     SPV_LAUNCH_CHECK("spv_patchify");
+    return 0;
+}
+
+extern "C" int spv_patchify_u8(const unsigned char* img_hwc, const float* mean, const float* inv_std, void* out, int batch,
+                               int chans, int height, int width, int patch, int ld, int transposed, int out_dtype, void* stream) {
+    SPV_CHECK(batch > 0 && chans > 0 && patch > 0 && height >= patch && width >= patch, "spv_patchify_u8: bad shape");
+    SPV_CHECK(out_dtype == SPV_F32 || out_dtype == SPV_BF16, "spv_patchify_u8: bad dtype");
+    SPV_CHECK(mean != nullptr && inv_std != nullptr, "spv_patchify_u8: mean / inv_std missing");
+    const int Np = (height / patch) * (width / patch), K = chans * patch * patch;
+    const int64_t rows = (int64_t)batch * Np;
+    SPV_CHECK(transposed ? ld >= rows : ld >= K, "spv_patchify_u8: ld=%d too small", ld);
+    const int64_t total = transposed ? (int64_t)K * ld : rows * ld;
+    hipLaunchKernelGGL(patchify_u8_kernel, dim3(ew_blocks(total)), dim3(256), 0, static_cast<hipStream_t>(stream), img_hwc, mean,
+                       inv_std, out, batch, chans, height, width, patch, ld, transposed, out_dtype == SPV_BF16);
+    SPV_LAUNCH_CHECK("spv_patchify_u8");
     return 0;
 }
 

@@ -61,18 +61,22 @@ class SyntheticCifar:
         self.mean = torch.tensor(CIFAR_MEAN[:c.in_channels], device=device).view(1, -1, 1, 1)
         self.std = torch.tensor(CIFAR_STD[:c.in_channels], device=device).view(1, -1, 1, 1)
 
-    def batches(self, batch_size, shuffle, generator=None, rank=0, world=1):
+    def batches(self, batch_size, shuffle, generator=None, rank=0, world=1, raw_uint8=False):
+        """raw_uint8: yield the uint8 NHWC batch itself; the model's patch gather normalises it."""
         n = self.images.shape[0]
         idx = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
         idx = idx[rank::world].to(self.images.device)
         for i in range(0, idx.numel() - batch_size + 1, batch_size):
             sel = idx[i:i + batch_size]
+            if raw_uint8:
+                yield self.images[sel].permute(0, 2, 3, 1).contiguous(), self.labels[sel]
+                continue
             img = (self.images[sel].float() / 255.0 - self.mean) / self.std
             yield img, self.labels[sel]
 
 
 def train(config_path, mixer="permut", epochs=1, steps_per_epoch=None, batch_size=None, n_train=4096, n_val=1024,
-          use_amp=True, distill=False, out_dir="runs/spectre_vit", log=print):
+          use_amp=True, distill=False, out_dir="runs/spectre_vit", log=print, uint8_input=False):
     c = parse_config(config_path)
     seed = getattr(c, "random_seed", 42)
     lr = getattr(c, "learning_rate", 1e-3)
@@ -104,7 +108,7 @@ def train(config_path, mixer="permut", epochs=1, steps_per_epoch=None, batch_siz
         running = torch.zeros((), device=device)
         correct = torch.zeros((), device=device, dtype=torch.int64)
         total, steps = 0, 0
-        for img, label in train_set.batches(batch_size, True, gen, rank, world):
+        for img, label in train_set.batches(batch_size, True, gen, rank, world, raw_uint8=uint8_input and not distill):
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp and not distill):  # distill: use_amp False, train.py:299
                 if distill:
                     student_logits, _ = model(img, return_features=True)
@@ -134,7 +138,7 @@ def train(config_path, mixer="permut", epochs=1, steps_per_epoch=None, batch_siz
         v_loss = torch.zeros((), device=device)
         v_total, v_steps = 0, 0
         with torch.no_grad():
-            for img, label in val_set.batches(min(c.val_batch_size, n_val), False, None, rank, world):
+            for img, label in val_set.batches(min(c.val_batch_size, n_val), False, None, rank, world, raw_uint8=uint8_input and not distill):
                 with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp and not distill):
                     y_pred = model(img)
                 v_correct += (label == torch.argmax(y_pred, dim=1)).sum()

@@ -587,20 +587,31 @@ class PatchEmbedFn(torch.autograd.Function):
     """tokens[b,0] = cls + pos[0]; tokens[b,1+n] = W_full . patch(b,n) + bias + pos[1+n]."""
 
     @staticmethod
-    def forward(ctx, img, w_full, bias, cls, pos, patch, dtype):
+    def forward(ctx, img, w_full, bias, cls, pos, patch, dtype, norm=None):
+        """img: float NCHW (the reference's input contract), or -- SURVEY 8f-3 -- the loader's uint8 NHWC batch with
+        norm = (mean[C], inv_std[C]) device tensors: /255 + Normalize are then folded into the patch gather."""
         _require_gpu(img, w_full)
-        B, C, H, W = img.shape
+        u8 = img.dtype == torch.uint8
+        if u8:
+            if norm is None:
+                raise ValueError("uint8 images need the (mean, inv_std) normalisation tensors")
+            B, H, W, C = img.shape
+        else:
+            B, C, H, W = img.shape
         E, K = w_full.shape
         Np = (H // patch) * (W // patch)
         T = Np + 1
         dev = img.device
-        img = img.contiguous().float()
+        img = img.contiguous() if u8 else img.contiguous().float()
         mult = 8 if dtype == torch.bfloat16 else 4
         if K % mult or E % mult:
             raise ValueError(f"patch embedding: C*P*P={K} and embed_dim={E} must be multiples of {mult}")
         st = _stream()
         patches = torch.empty((B * Np, K), dtype=dtype, device=dev)
-        _native.call("spv_patchify", _p(img), _p(patches), B, C, H, W, patch, K, 0, _DT[dtype], st)
+        if u8:
+            _native.call("spv_patchify_u8", _p(img), _p(norm[0]), _p(norm[1]), _p(patches), B, C, H, W, patch, K, 0, _DT[dtype], st)
+        else:
+            _native.call("spv_patchify", _p(img), _p(patches), B, C, H, W, patch, K, 0, _DT[dtype], st)
         wc = w_full if dtype == torch.float32 else _raw_cast(w_full, dtype)
         posbias = torch.empty((Np, E), dtype=torch.float32, device=dev)
         _native.call("spv_embed_posbias", _p(pos), _p(bias), _p(posbias), Np, E, st)
@@ -609,7 +620,7 @@ class PatchEmbedFn(torch.autograd.Function):
                      _DT[dtype], _DT[dtype], Np, T, 1, st)
         _native.call("spv_embed_cls_rows", _p(cls), _p(pos), _p(tokens), B, T, E, _DT[dtype], st)
         # bf16: the backward's TN weight-gradient GEMM reads the patch matrix as it lies here (3 MB), so keep it
-        ctx.save_for_backward(img, patches if dtype == torch.bfloat16 else None)
+        ctx.save_for_backward(None if u8 else img, patches if (dtype == torch.bfloat16 or u8) else None)
         ctx.meta = (B, C, H, W, patch, E, K, Np, T, dtype, cls.shape, pos.shape)
         return tokens
 
@@ -633,19 +644,58 @@ class PatchEmbedFn(torch.autograd.Function):
             pfull[:, 1:, :] = patches.view(B, Np, K)
             dwf = _weight_grad(dtok.view(B * T, E), pfull.view(B * T, K), B * T, E, K)
             join_side_stream()
-            return None, dwf, dbias, dcls, dpos.reshape(pos_shape), None, None
+            return None, dwf, dbias, dcls, dpos.reshape(pos_shape), None, None, None
         rows = B * Np
         ld = (rows + 7) // 8 * 8
         dyt = torch.empty((E, ld), dtype=dtok.dtype, device=dev)
         _native.call("spv_cast_transpose", _p(dtok), _dt(dtok), _p(dyt), _dt(dyt), rows, E, ld, Np, T, 1, st)
         pt = torch.empty((K, ld), dtype=dtok.dtype, device=dev)
-        _native.call("spv_patchify", _p(img), _p(pt), B, C, H, W, patch, ld, 1, _dt(pt), st)
+        if img is None:  # uint8 input: the forward kept the normalised patch matrix instead of a float image
+            _native.call("spv_cast_transpose", _p(patches), _dt(patches), _p(pt), _dt(pt), rows, K, ld, 0, 0, 0, st)
+        else:
+            _native.call("spv_patchify", _p(img), _p(pt), B, C, H, W, patch, ld, 1, _dt(pt), st)
         dwf = torch.empty((E, K), dtype=torch.float32, device=dev)
         tiles = ((E + 127) // 128) * ((K + 127) // 128)
         splits = max(1, min(1024 // tiles, (ld + 511) // 512))
         ws = torch.empty((splits * E * K,), dtype=torch.float32, device=dev) if splits > 1 else None
         _gemm(dyt, pt, None, dwf, E, K, ld, ld, ld, K, 0, splits, ws)
-        return None, dwf, dbias, dcls, dpos.reshape(pos_shape), None, None
+        return None, dwf, dbias, dcls, dpos.reshape(pos_shape), None, None, None
+
+
+# CIFAR-100 statistics of the reference loader (spectre_vit/repl/train.py:109-112)
+CIFAR100_MEAN = (0.5071, 0.4867, 0.4408)
+CIFAR100_STD = (0.2675, 0.2565, 0.2761)
+
+
+class PixelNorm:
+    """(mean, 1/std) per channel for uint8 NHWC input, kept as device tensors."""
+
+    def __init__(self, mean=CIFAR100_MEAN, std=CIFAR100_STD):
+        self.mean = tuple(float(m) for m in mean)
+        self.std = tuple(float(v) for v in std)
+        self._cache = {}
+
+    def tensors(self, device, channels):
+        if len(self.mean) != channels or len(self.std) != channels:
+            raise ValueError(f"pixel normalisation has {len(self.mean)} channels, the image has {channels}")
+        t = self._cache.get(device)
+        if t is None:
+            t = (torch.tensor(self.mean, dtype=torch.float32, device=device),
+                 torch.tensor([1.0 / v for v in self.std], dtype=torch.float32, device=device))
+            self._cache[device] = t
+        return t
+
+    def __deepcopy__(self, memo):
+        return PixelNorm(self.mean, self.std)
+
+
+def patch_embed(x, w_full, bias, cls, pos, patch, pixel_norm):
+    """float NCHW or uint8 NHWC images -> token tensor (B, 1 + patches, E)."""
+    if x.dtype == torch.uint8:
+        dt = torch.bfloat16 if torch.is_autocast_enabled("cuda") else torch.float32
+        norm = pixel_norm.tensors(x.device, x.shape[-1])
+        return PatchEmbedFn.apply(x, w_full, bias, cls, pos, patch, dt, norm)
+    return PatchEmbedFn.apply(x, w_full, bias, cls, pos, patch, compute_dtype(x))
 
 
 class DropoutFn(torch.autograd.Function):

@@ -120,12 +120,13 @@ class SpectralPatchEmbed(nn.Module):
         self.cls_token = nn.Parameter(torch.randn(1, 1, embed_dim))
         self.position_embeddings = nn.Parameter(torch.randn(1, num_patches + 1, embed_dim))
         self.dropout = nn.Dropout(dropout)
+        # extension: uint8 NHWC batches straight from the loader are normalised inside the patch gather
+        self.pixel_norm = hip_ops.PixelNorm()
 
     def forward(self, x):
-        dt = hip_ops.compute_dtype(x)
-        C = x.shape[1]
+        C = x.shape[-1] if x.dtype == torch.uint8 else x.shape[1]
         w_full = hip_ops.SpectralFoldFn.apply(self.proj.weight, self.freq_weight_h, self.freq_weight_w, C, self.P)
-        tok = hip_ops.PatchEmbedFn.apply(x, w_full, self.proj.bias, self.cls_token, self.position_embeddings, self.P, dt)
+        tok = hip_ops.patch_embed(x, w_full, self.proj.bias, self.cls_token, self.position_embeddings, self.P, self.pixel_norm)
         return hip_ops.dropout(tok, self.dropout.p, self.training)
 
 

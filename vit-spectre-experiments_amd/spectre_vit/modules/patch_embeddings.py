@@ -17,11 +17,12 @@ class PatchEmbedding(nn.Module):
         self.cls_token = nn.Parameter(torch.randn(1, 1, embed_dim))
         self.position_embeddings = nn.Parameter(torch.randn(1, num_patches + 1, embed_dim))
         self.dropout = nn.Dropout(p=dropout)
+        # extension: uint8 NHWC batches straight from the loader are normalised inside the patch gather
+        self.pixel_norm = hip_ops.PixelNorm()
 
     def forward(self, x):
         conv = self.patcher[0]
-        dt = hip_ops.compute_dtype(x)
         w_full = conv.weight.reshape(self.embed_dim, -1)
-        tok = hip_ops.PatchEmbedFn.apply(x, w_full, conv.bias, self.cls_token, self.position_embeddings,
-                                         conv.kernel_size[0], dt)
+        tok = hip_ops.patch_embed(x, w_full, conv.bias, self.cls_token, self.position_embeddings, conv.kernel_size[0],
+                                  self.pixel_norm)
         return hip_ops.dropout(tok, self.dropout.p, self.training)
