@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--mixer", default="fft", choices=["fft", "permut", "dwt_embed", "dwt_token"])
     ap.add_argument("--batch", type=int, default=512, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="spectre", choices=["spectre", "vit"],
+                    help="vit = the reference's baseline ViT (MHSA through the HIP attention kernels), not the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -118,7 +120,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     torch.manual_seed(42)
-    model = SpectreViT(**SMALL, mixer=args.mixer).to(dev)
+    if args.model == "vit":
+        from spectre_vit.models.vit.vit import ViT
+        model = ViT(**SMALL).to(dev)
+        args.no_cpu_baseline = True  # the CPU leg times the Spectre oracle
+    else:
+        model = SpectreViT(**SMALL, mixer=args.mixer).to(dev)
     broadcast_module(model)
     model.train()
     torch.manual_seed(1234 + rank)  # per-rank dropout / data streams
@@ -178,7 +185,8 @@ def main():
         ms = elapsed / args.steps * 1e3
         total_images = args.batch * world * args.steps
         rec = {
-            "metric": "images/sec training, Spectre-ViT-S CIFAR-100 bs512",
+            "metric": "images/sec training, Spectre-ViT-S CIFAR-100 bs512" if args.model == "spectre"
+                      else "images/sec training, baseline ViT-S CIFAR-100 bs512",
             "value": round(total_images / elapsed, 1),
             "unit": "images/sec",
             "n_gpus": world,
@@ -190,9 +198,11 @@ def main():
             "vs_baseline": None,
             "dtype": "bf16" if use_bf16 else "f32",
             "data": "synthetic CIFAR-shaped randn images / randint labels resident in HBM, random-init weights (seed 42)",
-            "config": {"workload": f"Spectre-ViT-Small (E512 H16 F768 L4 P4 N65, 100 classes, dropout 0.001), {args.mixer} mixer, "
-                                   f"train step fwd+CE+bwd+AdamW, bs {args.batch}/GPU",
-                       "mixer": args.mixer, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "config": {"workload": (f"Spectre-ViT-Small (E512 H16 F768 L4 P4 N65, 100 classes, dropout 0.001), {args.mixer} mixer, "
+                                    if args.model == "spectre" else
+                                    "baseline ViT-Small (E512 H16 F768 L4 P4 N65, MHSA with the reference's batch_first=False axis), ")
+                                   + f"train step fwd+CE+bwd+AdamW, bs {args.batch}/GPU",
+                       "mixer": args.mixer if args.model == "spectre" else "attention", "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "final_loss": round(final_loss, 4),
         }
         if timer is not None:

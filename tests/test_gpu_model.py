@@ -180,7 +180,8 @@ def test_state_dict_roundtrip_and_deepcopy():
 
 # ------------------------------------------------------------------------------------------------ baseline ViT
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("seqs,length,heads,hd", [(5, 7, 4, 4), (3, 130, 2, 32), (2, 512, 16, 32), (4, 65, 4, 16)])
+@pytest.mark.parametrize("seqs,length,heads,hd", [(5, 7, 4, 4), (3, 130, 2, 32), (2, 512, 16, 32), (4, 65, 4, 16), (3, 197, 3, 64),
+                                                  (2, 65, 16, 32), (1, 1, 2, 32)])
 def test_attention_core_vs_oracle(dtype, seqs, length, heads, hd):
     from spectre_vit import hip_ops
     rng = np.random.default_rng(seqs * 100 + length)

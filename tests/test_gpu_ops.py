@@ -375,6 +375,37 @@ def test_patch_embed_uint8_needs_matching_channels(ops):
     assert m(torch.zeros(2, 8, 8, 1, dtype=torch.uint8, device=dev())).shape == (2, 5, 64)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fft_approximator_and_binary_linear(ops, dtype):
+    """SURVEY 8f-4 side branches (reference layers.py:10-23, 104-121): plain contractions, oracle = x @ W^T in float64."""
+    from spectre_vit.models.spectre.layers import BinaryLinear, FFTApproximator
+    torch.manual_seed(2)
+    x = torch.randn(3, 65, 512, device=dev())
+    fa = FFTApproximator(512).to(dev())
+    bl = BinaryLinear(512, 96).to(dev())
+    tol = TOL[dtype]
+    for m in (fa, bl):
+        xin = x.clone().requires_grad_(True)
+        if dtype == torch.bfloat16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(xin)
+        else:
+            y = m(xin)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        W = n64(fa.weight) if m is fa else np.sign(n64(bl.weight)) * float(bl.scale)
+        xq, dq = q(n64(x), dtype), n64(dy)
+        name = type(m).__name__
+        check(y, xq @ W.T, tol, name + " y")
+        check(xin.grad, dq @ W, tol * 2, name + " dx")
+        if m is fa:
+            assert y.shape == (3, 65, 257)
+            check(fa.weight.grad, np.einsum("bno,bnd->od", dq, xq), tol * 2, name + " dW")
+        else:
+            assert bl.weight.grad is None or float(bl.weight.grad.abs().max()) == 0.0  # sign() passes no gradient
+            check(bl.scale.grad, np.array([(dq * (xq @ np.sign(n64(bl.weight)).T)).sum()]), tol * 4, name + " dscale")
+
+
 def test_dropout_kernel(ops):
     x = torch.ones(1 << 20, device=dev(), requires_grad=True)
     y = ops.DropoutFn.apply(x, 0.1)

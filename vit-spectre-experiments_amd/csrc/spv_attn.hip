@@ -9,7 +9,7 @@
 //
 // One wave per query row (forward, backward-1) or key row (backward-2): lanes over keys for the score row and the
 // softmax reductions, lanes over the head dimension for the P.V / dS.K products with the probabilities broadcast from
-// a wave-private LDS row.  First correct version of SURVEY row 8a-8; not yet an MFMA flash kernel.
+// a wave-private LDS row.  v1 (below) is the general fallback; v2 (further down) stages the operands in LDS.
 #include "spv_common.h"
 
 namespace {
@@ -185,6 +185,328 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const void* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// v2: the same arithmetic with the operands where the lanes can reach them.  K and V (forward, backward-1) or Q and dctx
+// (backward-2) of one (sequence, head) are staged ONCE per workgroup into LDS with 16-byte global loads, rows padded by
+// 8 bytes so that 8-byte LDS reads of consecutive rows are bank-conflict free; every inner product then reads LDS
+// instead of issuing one 2-byte global load per element (v1: 30 ms per layer-pass at len 512).  Used when head_dim is
+// 16 / 32 / 64 and the staged rows fit in LDS; v1 stays as the general fallback.
+template <typename T> __device__ __forceinline__ void lds_ld4(const unsigned char* p, float (&v)[4]);
+template <> __device__ __forceinline__ void lds_ld4<bf16_t>(const unsigned char* p, float (&v)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void lds_ld4<float>(const unsigned char* p, float (&v)[4]) {
+    const float2 a = *reinterpret_cast<const float2*>(p), b = *reinterpret_cast<const float2*>(p + 8);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+
+// stage `len` rows of HD elements (global row stride gstride elements) into LDS rows of RS bytes
+template <typename T, int HD>
+__device__ __forceinline__ void stage_rows(const T* __restrict__ g, size_t gstride, unsigned char* lds, int len) {
+    constexpr int RS = HD * (int)sizeof(T) + 8;
+    constexpr int CPR = HD * (int)sizeof(T) / 8;  // 8-byte chunks per row
+    for (int e = threadIdx.x; e < len * CPR; e += blockDim.x) {
+        const int r = e / CPR, c = e % CPR;
+        *reinterpret_cast<uint2*>(lds + (size_t)r * RS + c * 8) =
+            *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(g + (size_t)r * gstride) + c * 8);
+    }
+}
+
+constexpr int A2W = 8;  // waves per workgroup (forward, backward-1)
+
+template <typename T, int HD> struct A2 {
+    static constexpr int RS = HD * (int)sizeof(T) + 8;   // staged row stride in bytes
+    static constexpr int NG = HD / 4, NS = 64 / NG;       // P.V phase: NG lane groups over d (4 each) x NS key slices
+    static size_t lds_fwd(int len) { return (size_t)2 * len * RS + (size_t)A2W * (len + HD + NS * HD) * sizeof(float); }
+    static size_t lds_kv(int len) { return (size_t)2 * len * RS + (size_t)64 * (2 * HD + 1) * sizeof(float); }
+};
+
+// ctx row = softmax(q K^T) V for the rows of one chunk; `second` selects what the rows are contracted with afterwards
+template <typename T, int HD>
+__global__ __launch_bounds__(64 * A2W) void attn2_fwd_kernel(const T* __restrict__ qkv, T* __restrict__ ctx, T* __restrict__ probs,
+                                                             int len, int heads, int rows_per_wave, float p_drop, uint64_t seed) {
+    using P = A2<T, HD>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+    unsigned char* Ks = lds2;
+    unsigned char* Vs = lds2 + (size_t)len * P::RS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* prow = reinterpret_cast<float*>(lds2 + (size_t)2 * len * P::RS) + (size_t)wave * (len + HD + P::NS * HD);
+    float* qrow = prow + len;
+    float* red = qrow + HD;
+    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * HD;
+    const T* base = qkv + (size_t)s * len * 3 * E + h * HD;
+    stage_rows<T, HD>(base + E, (size_t)3 * E, Ks, len);
+    stage_rows<T, HD>(base + 2 * E, (size_t)3 * E, Vs, len);
+    __syncthreads();
+    const float scale = rsqrtf((float)HD);
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const int i0 = (blockIdx.y * A2W + wave) * rows_per_wave;
+    for (int i = i0; i < min(i0 + rows_per_wave, len); ++i) {
+        if (lane < HD) qrow[lane] = (float)io<T>::ld(base + (size_t)i * 3 * E + lane) * scale;
+        lds_sync();
+        float qv[HD];
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(qrow + d);
+            qv[d] = t4.x; qv[d + 1] = t4.y; qv[d + 2] = t4.z; qv[d + 3] = t4.w;
+        }
+        float sc[MAXC];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int k = c * 64 + lane;
+            sc[c] = -INFINITY;
+            if (c * 64 < len && k < len) {
+                const unsigned char* kr = Ks + (size_t)k * P::RS;
+                float a = 0.0f;
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    float kv[4];
+                    lds_ld4<T>(kr + d * sizeof(T), kv);
+                    a = fmaf(qv[d], kv[0], a); a = fmaf(qv[d + 1], kv[1], a); a = fmaf(qv[d + 2], kv[2], a); a = fmaf(qv[d + 3], kv[3], a);
+                }
+                sc[c] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c * 64 < len) {
+                sc[c] = (c * 64 + lane < len) ? __expf(sc[c] - mx) : 0.0f;
+                sum += sc[c];
+            }
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, i)) : 0u;
+        T* pg = probs + ((size_t)sh * len + i) * len;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int k = c * 64 + lane;
+            if (c * 64 < len && k < len) {
+                const float pv = sc[c] * inv;
+                io<T>::st(pg + k, pv);
+                prow[k] = p_drop > 0.0f ? pv * dropout_scale(rkey, (unsigned)k, p_drop, inv_keep) : pv;
+            }
+        }
+        lds_sync();
+        // ctx[i][:] = sum_k p[k] V[k][:]: lane = (d group of 4, key slice); slices meet in LDS
+        const int dg = lane % P::NG, ks = lane / P::NG;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = ks; k < len; k += P::NS) {
+            float vv[4];
+            lds_ld4<T>(Vs + (size_t)k * P::RS + dg * 4 * sizeof(T), vv);
+            const float pk = prow[k];
+            acc[0] = fmaf(pk, vv[0], acc[0]); acc[1] = fmaf(pk, vv[1], acc[1]); acc[2] = fmaf(pk, vv[2], acc[2]); acc[3] = fmaf(pk, vv[3], acc[3]);
+        }
+        *reinterpret_cast<float4*>(red + ks * HD + dg * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        lds_sync();
+        if (lane < HD) {
+            float o = 0.0f;
+#pragma unroll
+            for (int q = 0; q < P::NS; ++q) o += red[q * HD + lane];
+            io<T>::st(ctx + ((size_t)s * len + i) * E + h * HD + lane, o);
+        }
+        lds_sync();  // qrow / prow / red are rewritten by the next row
+    }
+}
+
+// backward 1: dS[i][:] = P (dP - <P, dP>) / sqrt(hd), dP = mask * (dctx[i] . V^T); dQ[i] = dS[i] . K
+template <typename T, int HD>
+__global__ __launch_bounds__(64 * A2W) void attn2_bwd_q_kernel(const T* __restrict__ dctx, const T* __restrict__ qkv,
+                                                               const T* __restrict__ probs, T* __restrict__ ds, T* __restrict__ dqkv,
+                                                               int len, int heads, int rows_per_wave, float p_drop, uint64_t seed) {
+    using P = A2<T, HD>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+    unsigned char* Ks = lds2;
+    unsigned char* Vs = lds2 + (size_t)len * P::RS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* srow = reinterpret_cast<float*>(lds2 + (size_t)2 * len * P::RS) + (size_t)wave * (len + HD + P::NS * HD);
+    float* grow = srow + len;
+    float* red = grow + HD;
+    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * HD;
+    const T* base = qkv + (size_t)s * len * 3 * E + h * HD;
+    stage_rows<T, HD>(base + E, (size_t)3 * E, Ks, len);
+    stage_rows<T, HD>(base + 2 * E, (size_t)3 * E, Vs, len);
+    __syncthreads();
+    const float scale = rsqrtf((float)HD);
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const int i0 = (blockIdx.y * A2W + wave) * rows_per_wave;
+    for (int i = i0; i < min(i0 + rows_per_wave, len); ++i) {
+        if (lane < HD) grow[lane] = (float)io<T>::ld(dctx + ((size_t)s * len + i) * E + h * HD + lane);
+        lds_sync();
+        float gv[HD];
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(grow + d);
+            gv[d] = t4.x; gv[d + 1] = t4.y; gv[d + 2] = t4.z; gv[d + 3] = t4.w;
+        }
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, i)) : 0u;
+        const size_t pg = ((size_t)sh * len + i) * len;
+        float dp[MAXC], pr[MAXC];
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int k = c * 64 + lane;
+            dp[c] = 0.0f;
+            pr[c] = 0.0f;
+            if (c * 64 < len && k < len) {
+                const unsigned char* vr = Vs + (size_t)k * P::RS;
+                float a = 0.0f;
+#pragma unroll
+                for (int d = 0; d < HD; d += 4) {
+                    float vv[4];
+                    lds_ld4<T>(vr + d * sizeof(T), vv);
+                    a = fmaf(gv[d], vv[0], a); a = fmaf(gv[d + 1], vv[1], a); a = fmaf(gv[d + 2], vv[2], a); a = fmaf(gv[d + 3], vv[3], a);
+                }
+                if (p_drop > 0.0f) a *= dropout_scale(rkey, (unsigned)k, p_drop, inv_keep);
+                dp[c] = a;
+                pr[c] = (float)io<T>::ld(probs + pg + k);
+                dot += pr[c] * a;
+            }
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int k = c * 64 + lane;
+            if (c * 64 < len && k < len) {
+                const float v = pr[c] * (dp[c] - dot) * scale;
+                io<T>::st(ds + pg + k, v);
+                srow[k] = v;
+            }
+        }
+        lds_sync();
+        const int dg = lane % P::NG, ks = lane / P::NG;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = ks; k < len; k += P::NS) {
+            float kv[4];
+            lds_ld4<T>(Ks + (size_t)k * P::RS + dg * 4 * sizeof(T), kv);
+            const float sk = srow[k];
+            acc[0] = fmaf(sk, kv[0], acc[0]); acc[1] = fmaf(sk, kv[1], acc[1]); acc[2] = fmaf(sk, kv[2], acc[2]); acc[3] = fmaf(sk, kv[3], acc[3]);
+        }
+        *reinterpret_cast<float4*>(red + ks * HD + dg * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        lds_sync();
+        if (lane < HD) {
+            float o = 0.0f;
+#pragma unroll
+            for (int q = 0; q < P::NS; ++q) o += red[q * HD + lane];
+            io<T>::st(dqkv + ((size_t)s * len + i) * 3 * E + h * HD + lane, o);
+        }
+        lds_sync();
+    }
+}
+
+// backward 2: one workgroup (4 waves) per 64 key rows, lane = key; the waves split the query rows, read P[i][keys] and
+// dS[i][keys] coalesced, and accumulate dV[key][:] += (mask P)[i][key] dctx[i][:], dK[key][:] += dS[i][key] Q[i][:] in
+// registers (Q and dctx rows broadcast from LDS); the four partial sums meet in LDS in wave order.
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn2_bwd_kv_kernel(const T* __restrict__ dctx, const T* __restrict__ qkv,
+                                                           const T* __restrict__ probs, const T* __restrict__ ds, T* __restrict__ dqkv,
+                                                           int len, int heads, float p_drop, uint64_t seed) {
+    using P = A2<T, HD>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+    unsigned char* Qs = lds2;
+    unsigned char* Gs = lds2 + (size_t)len * P::RS;
+    float* red = reinterpret_cast<float*>(lds2 + (size_t)2 * len * P::RS);  // [64 keys][2 HD + 1]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * HD;
+    stage_rows<T, HD>(qkv + (size_t)s * len * 3 * E + h * HD, (size_t)3 * E, Qs, len);
+    stage_rows<T, HD>(dctx + (size_t)s * len * E + h * HD, (size_t)E, Gs, len);
+    __syncthreads();
+    const int key = blockIdx.y * 64 + lane;
+    const bool live = key < len;
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    float ak[HD], av[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { ak[d] = 0.0f; av[d] = 0.0f; }
+    for (int i = wave; i < len; i += 4) {
+        const size_t e = ((size_t)sh * len + i) * len + key;
+        float pv = 0.0f, sv = 0.0f;
+        if (live) {
+            pv = (float)io<T>::ld(probs + e);
+            sv = (float)io<T>::ld(ds + e);
+            if (p_drop > 0.0f) pv *= dropout_scale(dropout_row_key(seed, attn_row(sh, len, i)), (unsigned)key, p_drop, inv_keep);
+        }
+        const unsigned char* qr = Qs + (size_t)i * P::RS;
+        const unsigned char* gr = Gs + (size_t)i * P::RS;
+#pragma unroll
+        for (int d = 0; d < HD; d += 4) {
+            float qv[4], gv[4];
+            lds_ld4<T>(qr + d * sizeof(T), qv);  // same address in every lane: LDS broadcast
+            lds_ld4<T>(gr + d * sizeof(T), gv);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ak[d + u] = fmaf(sv, qv[u], ak[d + u]); av[d + u] = fmaf(pv, gv[u], av[d + u]); }
+        }
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+            float* r = red + (size_t)lane * (2 * HD + 1);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                r[d] = (w == 0 ? 0.0f : r[d]) + ak[d];
+                r[HD + d] = (w == 0 ? 0.0f : r[HD + d]) + av[d];
+            }
+        }
+        __syncthreads();
+    }
+    // write dK | dV rows: thread t -> (key t / 4, quarter of the 2 HD columns)
+    for (int e = threadIdx.x; e < 64 * 2 * HD; e += 256) {
+        const int kk = e / (2 * HD), c = e % (2 * HD);
+        const int kg = blockIdx.y * 64 + kk;
+        if (kg < len) io<T>::st(dqkv + ((size_t)s * len + kg) * 3 * E + (c < HD ? E : 2 * E - HD) + h * HD + c, red[(size_t)kk * (2 * HD + 1) + c]);
+    }
+}
+
+constexpr size_t A2_LDS_MAX = 150 * 1024;
+
+template <typename T, int HD>
+int launch_attn2_fwd(const void* qkv, void* ctx, void* probs, int seqs, int len, int heads, float p_drop, uint64_t seed, hipStream_t st) {
+    const size_t lds = A2<T, HD>::lds_fwd(len);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int rpw = std::max(1, std::min(16, cdiv(len, A2W)));
+    dim3 grid(seqs * heads, cdiv(len, A2W * rpw));
+    hipLaunchKernelGGL((attn2_fwd_kernel<T, HD>), grid, dim3(64 * A2W), lds, st, (const T*)qkv, (T*)ctx, (T*)probs, len, heads, rpw, p_drop, seed);
+    SPV_LAUNCH_CHECK("spv_attention_fwd(v2)");
+    return 0;
+}
+template <typename T, int HD>
+int launch_attn2_bwd(const void* dctx, const void* qkv, const void* probs, void* ds, void* dqkv, int seqs, int len, int heads,
+                     float p_drop, uint64_t seed, hipStream_t st) {
+    const size_t lds = A2<T, HD>::lds_fwd(len), lds_kv = A2<T, HD>::lds_kv(len);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_bwd_q_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_bwd_kv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    const int rpw = std::max(1, std::min(16, cdiv(len, A2W)));
+    dim3 grid(seqs * heads, cdiv(len, A2W * rpw));
+    hipLaunchKernelGGL((attn2_bwd_q_kernel<T, HD>), grid, dim3(64 * A2W), lds, st, (const T*)dctx, (const T*)qkv, (const T*)probs, (T*)ds,
+                       (T*)dqkv, len, heads, rpw, p_drop, seed);
+    SPV_LAUNCH_CHECK("spv_attention_bwd(v2 q)");
+    hipLaunchKernelGGL((attn2_bwd_kv_kernel<T, HD>), dim3(seqs * heads, cdiv(len, 64)), dim3(256), lds_kv, st, (const T*)dctx,
+                       (const T*)qkv, (const T*)probs, (const T*)ds, (T*)dqkv, len, heads, p_drop, seed);
+    SPV_LAUNCH_CHECK("spv_attention_bwd(v2 kv)");
+    return 0;
+}
+
+// v2 applies when head_dim is 16 / 32 / 64, rows are 8-byte aligned and the staged operands fit in LDS
+template <typename T> inline bool attn2_ok(int len, int heads, int hd, const void* a, const void* b) {
+    if (!(hd == 16 || hd == 32 || hd == 64)) return false;
+    if (((uintptr_t)a & 7) || ((uintptr_t)b & 7) || ((size_t)heads * hd * sizeof(T)) % 8) return false;
+    const size_t rs = hd * sizeof(T) + 8;
+    const size_t f = (size_t)2 * len * rs + (size_t)A2W * (len + hd + 64 / (hd / 4) * hd) * sizeof(float);
+    const size_t kv = (size_t)2 * len * rs + (size_t)64 * (2 * hd + 1) * sizeof(float);
+    return f <= A2_LDS_MAX && kv <= A2_LDS_MAX;
+}
+
+#define A2_DISPATCH(T, hd, FN, ...)                          \
+    do {                                                     \
+        if (hd == 16) return FN<T, 16>(__VA_ARGS__);         \
+        if (hd == 32) return FN<T, 32>(__VA_ARGS__);         \
+        return FN<T, 64>(__VA_ARGS__);                       \
+    } while (0)
+
 int check(const char* name, int seqs, int len, int heads, int hd, int dtype) {
     SPV_CHECK(seqs > 0 && len > 0 && heads > 0 && hd > 0, "%s: empty", name);
     SPV_CHECK(len <= 64 * MAXC, "%s: len=%d > %d", name, len, 64 * MAXC);
@@ -198,6 +520,10 @@ int check(const char* name, int seqs, int len, int heads, int hd, int dtype) {
 extern "C" int spv_attention_fwd(const void* qkv, void* ctx, void* probs, int seqs, int len, int heads, int head_dim, int dtype,
                                  float p_drop, uint64_t seed, void* stream) {
     if (check("spv_attention_fwd", seqs, len, heads, head_dim, dtype)) return 1;
+    if (dtype == SPV_BF16 && attn2_ok<bf16_t>(len, heads, head_dim, qkv, ctx))
+        A2_DISPATCH(bf16_t, head_dim, launch_attn2_fwd, qkv, ctx, probs, seqs, len, heads, p_drop, seed, static_cast<hipStream_t>(stream));
+    if (dtype == SPV_F32 && attn2_ok<float>(len, heads, head_dim, qkv, ctx))
+        A2_DISPATCH(float, head_dim, launch_attn2_fwd, qkv, ctx, probs, seqs, len, heads, p_drop, seed, static_cast<hipStream_t>(stream));
     dim3 grid(seqs * heads, cdiv(len, AW));
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(64 * AW), (size_t)AW * (len + MAXHD) * sizeof(float), static_cast<hipStream_t>(stream),
                        qkv, ctx, probs, len, heads, head_dim, dtype == SPV_BF16, p_drop, seed);
@@ -209,6 +535,10 @@ extern "C" int spv_attention_bwd(const void* dctx, const void* qkv, const void* 
                                  int heads, int head_dim, int dtype, float p_drop, uint64_t seed, void* stream) {
     if (check("spv_attention_bwd", seqs, len, heads, head_dim, dtype)) return 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SPV_BF16 && attn2_ok<bf16_t>(len, heads, head_dim, qkv, dctx))
+        A2_DISPATCH(bf16_t, head_dim, launch_attn2_bwd, dctx, qkv, probs, dscores, dqkv, seqs, len, heads, p_drop, seed, st);
+    if (dtype == SPV_F32 && attn2_ok<float>(len, heads, head_dim, qkv, dctx))
+        A2_DISPATCH(float, head_dim, launch_attn2_bwd, dctx, qkv, probs, dscores, dqkv, seqs, len, heads, p_drop, seed, st);
     dim3 grid(seqs * heads, cdiv(len, AW));
     hipLaunchKernelGGL(attn_bwd_q_kernel, grid, dim3(64 * AW), (size_t)AW * (len + MAXHD) * sizeof(float), st, dctx, qkv, probs, dscores,
                        dqkv, len, heads, head_dim, dtype == SPV_BF16, p_drop, seed);

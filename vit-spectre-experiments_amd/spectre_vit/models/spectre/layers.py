@@ -7,6 +7,7 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from spectre_vit import hip_ops
 from spectre_vit.modules.spectre import FFT  # noqa: F401  (the reference imports it here too: layers.py:7)
@@ -94,8 +95,19 @@ class MHPermutMix(nn.Module):
         return self.linear(g.view(B, self.token_dim, self.concat_dim))
 
 
+def _padded_linear(x, weight):
+    """x @ weight^T on the MFMA GEMM for an output width that is not a multiple of the 16-byte chunk (257 = D//2+1):
+    the weight is zero-padded to the next multiple of 8 rows and the extra columns are sliced away again."""
+    n = weight.shape[0]
+    npad = (n + 7) // 8 * 8
+    w = F.pad(weight, (0, 0, 0, npad - n)) if npad != n else weight
+    dt = hip_ops.compute_dtype(x)
+    y = hip_ops.linear(hip_ops.cast(x, dt), w, None)
+    return y[..., :n] if npad != n else y
+
+
 class FFTApproximator(nn.Module):
-    """Learned stand-in for rfft: x @ W^T with W (D//2+1, D)  (reference layers.py:104-121)."""
+    """Learned stand-in for rfft: x @ W^T with W (D//2+1, D)  (reference layers.py:104-121; SURVEY 8f-4)."""
 
     def __init__(self, dim) -> None:
         super().__init__()
@@ -104,5 +116,20 @@ class FFTApproximator(nn.Module):
         self.weight = nn.Parameter(torch.randn(self.out_dim, self.dim))
 
     def forward(self, x):
-        raise NotImplementedError("FFTApproximator is a research side branch that no reference model instantiates "
-                                  "(SURVEY.md 8f-4); not built yet")
+        return _padded_linear(x, self.weight)
+
+
+class BinaryLinear(nn.Module):
+    """scale * (x @ sign(W)^T)  (reference layers.py:10-23; sign() passes no gradient to W, as in the reference)."""
+
+    def __init__(self, in_features, out_features, requires_grad=True):
+        super().__init__()
+        if requires_grad:
+            self.weight = nn.Parameter(torch.randn(out_features, in_features))
+        else:
+            self.weight = nn.Parameter(torch.ones(out_features, in_features), requires_grad=False)
+        self.scale = nn.Parameter(torch.ones(1), requires_grad=requires_grad)
+
+    def forward(self, x):
+        y = _padded_linear(x, self.weight.sign())
+        return self.scale.to(y.dtype) * y
