@@ -303,6 +303,105 @@ static double check_rows(const std::vector<bf16_t>& hA, const std::vector<bf16_t
     return worst;
 }
 
+// 128 x (64 WN) tile, 2 x WN waves of 64 x 64 each (WN = 4: 128 x 256, 512 threads): same wave tile as the 128 x 128 kernel,
+// 25 % fewer operand bytes through the L2 -> LDS path
+template <int WN, int NST, int ABL>
+__global__ __launch_bounds__(128 * WN) void lab_kernel_n(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C,
+                                                         int M, int N, int K, int tiles_n, int tiles_mn) {
+    constexpr int NWV = 2 * WN, TBN = 64 * WN, KB = 64, KE = KB / 2;
+    constexpr int STAGE = (128 + TBN) * KB;
+    constexpr int NI = (128 + TBN) / 16;  // DMA instructions per stage (16 rows each)
+    constexpr int IPW = NI / NWV;         // per wave (WN = 4: 24 / 8 = 3; WN = 2: 16 / 4 = 4)
+    constexpr int SM = NST * STAGE > NWV * 9216 ? NST * STAGE : NWV * 9216;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tile = xcd_remap(blockIdx.x, tiles_mn);
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    const int m0 = tm * 128, n0 = tn * TBN;
+    const bf16_t* src[IPW];
+#pragma unroll
+    for (int t = 0; t < IPW; ++t) {
+        const int R = 16 * (wave * IPW + t) + (lane >> 2);  // stage row: A rows 0..127 then B rows
+        const int c = (lane & 3) ^ ((R >> 2) & 3);
+        src[t] = R < 128 ? A + (size_t)min(m0 + R, M - 1) * K + c * 8 : B + (size_t)min(n0 + R - 128, N - 1) * K + c * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+        unsigned char* d = smem + buf * STAGE + wave * IPW * 1024;
+#pragma unroll
+        for (int t = 0; t < IPW; ++t)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[t] + k0),
+                                             (__attribute__((address_space(3))) void*)(d + t * 1024), 16, 0, 0);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 2) & 3;
+    const int fa_off = (wm * 64 + frow) * KB, fb_off = (128 + wn * 64 + frow) * KB;
+    const int nk = K / KE;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) stage(s, s * KE);
+    int buf = 0;
+    for (int t = 0; t < nk; ++t) {
+        if (NST >= 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + NST - 1 < nk) stage((buf + NST - 1) % NST, (t + NST - 1) * KE);
+        const unsigned char* sa = smem + buf * STAGE + fa_off;
+        const unsigned char* sb = smem + buf * STAGE + fb_off;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int ch = ((ks * 2 + fh) ^ swz) * 16;
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f] = *reinterpret_cast<const bf16x8*>(sa + f * 32 * KB + ch);
+                b[f] = *reinterpret_cast<const bf16x8*>(sb + f * 32 * KB + ch);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        buf = (buf + 1 == NST) ? 0 : buf + 1;
+    }
+    if (ABL & 1) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        if (s == 1234.5678f) C[0] = 1;
+        return;
+    }
+    store_acc_tile<bf16_t>(acc, smem, nullptr, C, nullptr, M, N, N, 0, m0, n0, 0, 0, 0, 0, nullptr, nullptr, 0, 0, wm * 64, wn * 64);
+}
+
+template <int WN, int NST, int ABL>
+float run_n(const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, int iters) {
+    const int tiles_n = N / (64 * WN), tiles_m = (M + 127) / 128;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i)
+        hipLaunchKernelGGL((lab_kernel_n<WN, NST, ABL>), dim3(tiles_m * tiles_n), dim3(128 * WN), 0, 0, A, B, C, M, N, K, tiles_n, tiles_m * tiles_n);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL((lab_kernel_n<WN, NST, ABL>), dim3(tiles_m * tiles_n), dim3(128 * WN), 0, 0, A, B, C, M, N, K, tiles_n, tiles_m * tiles_n);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms * 1e3f / iters;
+}
+
 template <int WMB, int NST, int ABL>
 float run(const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, int iters) {
     const int tiles_n = N / BN, tiles_m = (M + 64 * WMB - 1) / (64 * WMB);
@@ -367,6 +466,20 @@ int main(int argc, char** argv) {
         printf("tile %3dx128 stages %d %-34s %8.2f us  %7.1f TFLOP/s\n", 64 * W, S, label, us, gf / us); \
         fflush(stdout);                                                                           \
     }
+#define RUNN(WN, S, ABL, label)                                                                   \
+    {                                                                                             \
+        float us = run_n<WN, S, ABL>(A, B, C, M, N, K, 20);                                       \
+        printf("tile 128x%3d stages %d %-34s %8.2f us  %7.1f TFLOP/s", 64 * WN, S, label, us, gf / us); \
+        if (ABL == 0) printf("  max rel err %.2e", check_rows(h, hB, C, M, N, K));                \
+        printf("\n");                                                                             \
+        fflush(stdout);                                                                           \
+    }
+    RUNN(4, 2, 0, "8 waves full")
+    RUNN(4, 2, 1, "8 waves no C store")
+    RUNN(4, 3, 0, "8 waves full")
+    RUNN(4, 3, 1, "8 waves no C store")
+    RUNN(2, 2, 0, "4 waves full")
+    RUNN(2, 3, 0, "4 waves full")
     RUN(2, 2, 0, "full")
     RUN(2, 2, 1, "no C store")
     RUN(2, 2, 2, "B staged once")
@@ -377,12 +490,6 @@ int main(int argc, char** argv) {
     RUN(2, 2, 9, "no MFMA, no C store")
     RUN(2, 3, 0, "full")
     RUN(2, 3, 1, "no C store")
-    RUN(2, 2, 16, "interleaved glds")
-    RUN(2, 2, 17, "interleaved glds, no C store")
-    RUN(2, 3, 16, "interleaved glds")
-    RUN(2, 3, 17, "interleaved glds, no C store")
-    RUN(4, 2, 16, "interleaved glds")
-    RUN(4, 2, 17, "interleaved glds, no C store")
     RUN(4, 2, 0, "full")
     RUN(4, 2, 1, "no C store")
     RUN(4, 2, 6, "A and B staged once")

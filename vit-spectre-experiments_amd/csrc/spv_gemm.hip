@@ -47,11 +47,13 @@ __device__ __forceinline__ void store_acc_tile(f32x16 (*acc)[2], unsigned char* 
                                                TO* __restrict__ C, float* __restrict__ ws, int M, int N, int ldc, int accumulate,
                                                int m0, int n0, int split, int rg, int gs, int roff,
                                                const float* __restrict__ bias2d, const void* __restrict__ bc = nullptr,
-                                               int bc_pw = 0, int bc_bf = 0, int wrow = -1) {
+                                               int bc_pw = 0, int bc_bf = 0, int wrow = -1, int wcol = -1) {
     // acc: two rows of two 32x32 accumulators = this wave's 64 x 64 block at tile rows wrow.. (default (wave >> 1) * 64)
+    // and tile columns wcol.. (default (wave & 1) * 64)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wn = wave & 1, fh = lane >> 5;
+    const int fh = lane >> 5;
     if (wrow < 0) wrow = (wave >> 1) * 64;
+    if (wcol < 0) wcol = (wave & 1) * 64;
     float* stage = reinterpret_cast<float*>(smem + wave * 9216);  // 9216 B per wave >= 32 * 68 * 4
     constexpr int SLD = 68;
     const bool vec_c = ((size_t)ldc * sizeof(TO)) % 16 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
@@ -70,7 +72,7 @@ __device__ __forceinline__ void store_acc_tile(f32x16 (*acc)[2], unsigned char* 
             const int qd = lane + 64 * t;
             const int lr = qd >> 3, c8 = qd & 7;
             const int row = m0 + wrow + i * 32 + lr;
-            const int col0 = n0 + wn * 64 + c8 * 8;
+            const int col0 = n0 + wcol + c8 * 8;
             if (row >= M || col0 >= N) continue;
             float v[8];
             {

@@ -201,6 +201,14 @@ def set_kernel_timer(t):
 
 
 def _gemm(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspace=None):
+    if splits == 1 and K >= 256:
+        # a handful of output tiles (the 512 x 100 classifier head: 4) would run on a handful of CUs for the whole K
+        # loop -- 42 us for 52 MFLOP in fp32; split the reduction so that ~256 workgroups share it
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        if tiles <= 32:
+            splits = max(1, min(K // 64, 256 // tiles))
+            if splits > 1:
+                workspace = torch.empty((splits * M * N,), dtype=torch.float32, device=c.device)
     if _timer is not None:
         _timer.bracket("gemm", (M, N, K, _dt(a)), lambda: _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate, splits,
                                                                         workspace))
@@ -240,7 +248,7 @@ def _weight_grad(dh, x, rows, n, k, sink=None):
     dw = _grad_buf(sink, (n, k), dev)
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
     # ~2 workgroups per CU: measured optimum on the 768 x 512 x 33280 weight gradient (21 splits: 51 us; 12: 69; 42: 56; 64: 64)
-    splits = max(1, min(512 // tiles, (rows + 511) // 512))
+    splits = max(1, min(512 // tiles, (rows + 511) // 512 if tiles >= 8 else (rows + 63) // 64))
     ws = None
     if dh.dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0:
         def launch():
