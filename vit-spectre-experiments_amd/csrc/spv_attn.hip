@@ -507,6 +507,306 @@ template <typename T> inline bool attn2_ok(int len, int heads, int hd, const voi
         return FN<T, 64>(__VA_ARGS__);                       \
     } while (0)
 
+// ------------------------------------------------------------------------------------------------------------------
+// v3 (bf16, head_dim 32): both contractions on MFMA, nothing of size len x len stored.
+//
+// A wave owns 32 queries (forward, backward-1) or 32 keys (backward-2) and walks the other axis in blocks of 32.  The
+// score block is computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_bf16, 2 per block), so a lane owns one query
+// (forward / backward-1) resp. one key (backward-2) and its 16 accumulator registers are 16 entries of that row:
+// softmax statistics are in-register maxima / sums plus one exchange between the two 32-lane halves.  The register
+// layout of the accumulator (row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) is, 8 registers at a time, exactly an MFMA
+// operand whose k slot (g, j) holds entry 16 t + 4 g + (j & 3) + 8 (j >> 2): P (or dS) goes into the second product
+// straight from registers, and the other operand is read from a TRANSPOSED LDS copy (V^T, K^T, Q^T, dctx^T: rows = head
+// dim, columns = sequence, two 8-byte reads per k16 step at sequence offsets 16 t + 4 g and + 8).
+// Forward: pass 1 row max / sum, pass 2 P = exp(s - m) / l -> O^T += V^T P^T; the row log-sum-exp is kept instead of P.
+// Backward recomputes P from it: backward-1 (per query) delta = sum_k P dP, dS = P (dP - delta) / sqrt(hd), dQ^T += K^T dS^T;
+// backward-2 (per key) dV^T.. as dV = (mask P)^T dctx, dK = dS^T Q with P / dS as the register operand.
+// The `probs` / `dscores` arguments of the C-ABI are used as scratch for lse / delta (seqs*heads*len floats each).
+typedef __attribute__((ext_vector_type(4))) short a3s4;
+typedef __attribute__((ext_vector_type(8))) short a3s8;
+
+__device__ __forceinline__ bf16x8 a3_ld16(const bf16_t* p) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
+}
+// two 8-byte LDS reads -> one k16 operand (sequence entries +0..3 and +8..11)
+__device__ __forceinline__ bf16x8 a3_ldt(const bf16_t* row) {
+    const a3s4 lo = *reinterpret_cast<const a3s4*>(row), hi = *reinterpret_cast<const a3s4*>(row + 8);
+    const a3s8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 a3_pack(const float (&v)[16], int t) {
+    a3s8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(v[8 * t + j]);
+    return __builtin_bit_cast(bf16x8, o);
+}
+// stage src rows [len][32] (row stride gstride elements) transposed into dst[32][LP], zero beyond len (LR = LP - 4 columns)
+__device__ __forceinline__ void a3_stage_t(const bf16_t* __restrict__ src, size_t gstride, bf16_t* dst, int len, int LP) {
+    const int LR = LP - 4;
+    for (int e = threadIdx.x; e < LR * 4; e += blockDim.x) {
+        const int key = e >> 2, c = e & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < len) v = *reinterpret_cast<const uint4*>(src + (size_t)key * gstride + c * 8);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            dst[(size_t)(c * 8 + 2 * u) * LP + key] = (bf16_t)(w[u] & 0xffffu);
+            dst[(size_t)(c * 8 + 2 * u + 1) * LP + key] = (bf16_t)(w[u] >> 16);
+        }
+    }
+}
+// entry index inside a 32-block of accumulator register r for lane half g
+__device__ __forceinline__ int a3_idx(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+template <bool WRITE_P>
+__global__ __launch_bounds__(256) void attn3_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                        bf16_t* __restrict__ probs, float* __restrict__ lse, int len, int heads,
+                                                        float p_drop, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    bf16_t* Vt = reinterpret_cast<bf16_t*>(lds3);
+    const int LR = (len + 31) & ~31, LP = LR + 4;
+    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * 32;
+    const bf16_t* base = qkv + (size_t)s * len * 3 * E + h * 32;
+    a3_stage_t(base + 2 * E, (size_t)3 * E, Vt, len, LP);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, c = lane & 31;
+    const int q0 = (blockIdx.y * 4 + wave) * 32;
+    if (q0 >= len) return;
+    const int q = q0 + c, qi = min(q, len - 1);
+    const bf16x8 qb0 = a3_ld16(base + (size_t)qi * 3 * E + 8 * g), qb1 = a3_ld16(base + (size_t)qi * 3 * E + 16 + 8 * g);
+    const float scale = rsqrtf(32.0f);
+    const int nb = LR >> 5;
+    float m = -INFINITY, l = 0.0f;
+    for (int kb = 0; kb < nb; ++kb) {
+        const int ki = min(kb * 32 + c, len - 1);
+        const bf16_t* kr = base + E + (size_t)ki * 3 * E + 8 * g;
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr), qb0, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr + 16), qb1, S, 0, 0, 0);
+        float bm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            S[r] = (kb * 32 + a3_idx(r, g) < len) ? S[r] * scale : -INFINITY;
+            bm = fmaxf(bm, S[r]);
+        }
+        if (bm > -INFINITY) {
+            const float mn = fmaxf(m, bm);
+            float a = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a += __expf(S[r] - mn);
+            l = l * __expf(m - mn) + a;
+            m = mn;
+        }
+    }
+    {
+        const float mo = __shfl_xor(m, 32), lo = __shfl_xor(l, 32);
+        const float M = fmaxf(m, mo);
+        l = l * __expf(m - M) + lo * __expf(mo - M);
+        m = M;
+    }
+    const float inv = 1.0f / l;
+    if (g == 0 && q < len) lse[(size_t)sh * len + q] = m + __logf(l);
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, qi)) : 0u;
+    f32x16 O;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[r] = 0.0f;
+    for (int kb = 0; kb < nb; ++kb) {
+        const int ki = min(kb * 32 + c, len - 1);
+        const bf16_t* kr = base + E + (size_t)ki * 3 * E + 8 * g;
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr), qb0, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr + 16), qb1, S, 0, 0, 0);
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + a3_idx(r, g);
+            pv[r] = key < len ? __expf(S[r] * scale - m) * inv : 0.0f;
+        }
+        if (WRITE_P && q < len) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + a3_idx(r, g);
+                if (key < len) probs[((size_t)sh * len + q) * len + key] = f2bf(pv[r]);
+            }
+        }
+        if (p_drop > 0.0f) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[r] *= dropout_scale(rkey, (unsigned)(kb * 32 + a3_idx(r, g)), p_drop, inv_keep);
+        }
+        const bf16_t* vr = Vt + (size_t)c * LP + kb * 32 + 4 * g;
+        O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(vr), a3_pack(pv, 0), O, 0, 0, 0);
+        O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(vr + 16), a3_pack(pv, 1), O, 0, 0, 0);
+    }
+    if (q < len) {
+        bf16_t* o = ctx + ((size_t)s * len + q) * E + h * 32 + 4 * g;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            uint2 w;
+            w.x = (unsigned)f2bf(O[4 * qd]) | ((unsigned)f2bf(O[4 * qd + 1]) << 16);
+            w.y = (unsigned)f2bf(O[4 * qd + 2]) | ((unsigned)f2bf(O[4 * qd + 3]) << 16);
+            *reinterpret_cast<uint2*>(o + 8 * qd) = w;
+        }
+    }
+}
+
+// backward 1: per wave 32 queries.  delta[q] = sum_k P dP', dS = P (dP' - delta) / sqrt(hd), dQ^T += K^T dS^T  (dP' = mask dP)
+__global__ __launch_bounds__(256) void attn3_bwd_q_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ qkv,
+                                                          const float* __restrict__ lse, float* __restrict__ delta,
+                                                          bf16_t* __restrict__ dqkv, int len, int heads, float p_drop, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    bf16_t* Kt = reinterpret_cast<bf16_t*>(lds3);
+    const int LR = (len + 31) & ~31, LP = LR + 4;
+    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * 32;
+    const bf16_t* base = qkv + (size_t)s * len * 3 * E + h * 32;
+    a3_stage_t(base + E, (size_t)3 * E, Kt, len, LP);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, c = lane & 31;
+    const int q0 = (blockIdx.y * 4 + wave) * 32;
+    if (q0 >= len) return;
+    const int q = q0 + c, qi = min(q, len - 1);
+    const bf16x8 qb0 = a3_ld16(base + (size_t)qi * 3 * E + 8 * g), qb1 = a3_ld16(base + (size_t)qi * 3 * E + 16 + 8 * g);
+    const bf16_t* gr = dctx + ((size_t)s * len + qi) * E + h * 32 + 8 * g;
+    const bf16x8 gb0 = a3_ld16(gr), gb1 = a3_ld16(gr + 16);
+    const float scale = rsqrtf(32.0f);
+    const float lq = lse[(size_t)sh * len + qi];
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, qi)) : 0u;
+    const int nb = LR >> 5;
+    float dot = 0.0f;
+    f32x16 dQ;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQ[r] = 0.0f;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int kb = 0; kb < nb; ++kb) {
+            const int ki = min(kb * 32 + c, len - 1);
+            const bf16_t* kr = base + E + (size_t)ki * 3 * E + 8 * g;
+            f32x16 S, dP;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[r] = 0.0f; dP[r] = 0.0f; }
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr), qb0, S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr + 16), qb1, S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr + E), gb0, dP, 0, 0, 0);        // V row = K row + E
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr + E + 16), gb1, dP, 0, 0, 0);
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + a3_idx(r, g);
+                const float pv = key < len ? __expf(S[r] * scale - lq) : 0.0f;
+                float dp = dP[r];
+                if (p_drop > 0.0f) dp *= dropout_scale(rkey, (unsigned)key, p_drop, inv_keep);
+                if (pass == 0) dot += pv * dp;
+                else ds[r] = pv * (dp - dot) * scale;
+            }
+            if (pass == 1) {
+                const bf16_t* ktr = Kt + (size_t)c * LP + kb * 32 + 4 * g;
+                dQ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(ktr), a3_pack(ds, 0), dQ, 0, 0, 0);
+                dQ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(ktr + 16), a3_pack(ds, 1), dQ, 0, 0, 0);
+            }
+        }
+        if (pass == 0) {
+            dot += __shfl_xor(dot, 32);
+            if (g == 0 && q < len) delta[(size_t)sh * len + q] = dot;
+        }
+    }
+    if (q < len) {
+        bf16_t* o = dqkv + ((size_t)s * len + q) * 3 * E + h * 32 + 4 * g;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            uint2 w;
+            w.x = (unsigned)f2bf(dQ[4 * qd]) | ((unsigned)f2bf(dQ[4 * qd + 1]) << 16);
+            w.y = (unsigned)f2bf(dQ[4 * qd + 2]) | ((unsigned)f2bf(dQ[4 * qd + 3]) << 16);
+            *reinterpret_cast<uint2*>(o + 8 * qd) = w;
+        }
+    }
+}
+
+// backward 2: per wave 32 keys.  S = Q K^T with lane = key; dV += (mask P)^T dctx, dK += dS^T Q
+__global__ __launch_bounds__(256) void attn3_bwd_kv_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ qkv,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           bf16_t* __restrict__ dqkv, int len, int heads, float p_drop, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
+    const int LR = (len + 31) & ~31, LP = LR + 4;
+    bf16_t* Qt = reinterpret_cast<bf16_t*>(lds3);
+    bf16_t* Gt = Qt + (size_t)32 * LP;
+    float* lse_s = reinterpret_cast<float*>(Gt + (size_t)32 * LP);
+    float* del_s = lse_s + LR;
+    unsigned* rk_s = reinterpret_cast<unsigned*>(del_s + LR);
+    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * 32;
+    const bf16_t* base = qkv + (size_t)s * len * 3 * E + h * 32;
+    const bf16_t* gbase = dctx + (size_t)s * len * E + h * 32;
+    a3_stage_t(base, (size_t)3 * E, Qt, len, LP);
+    a3_stage_t(gbase, (size_t)E, Gt, len, LP);
+    for (int i = threadIdx.x; i < LR; i += blockDim.x) {
+        const bool ok = i < len;
+        lse_s[i] = ok ? lse[(size_t)sh * len + i] : 0.0f;
+        del_s[i] = ok ? delta[(size_t)sh * len + i] : 0.0f;
+        rk_s[i] = (ok && p_drop > 0.0f) ? dropout_row_key(seed, attn_row(sh, len, i)) : 0u;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, c = lane & 31;
+    const int k0 = (blockIdx.y * 4 + wave) * 32;
+    if (k0 >= len) return;
+    const int key = k0 + c, ki = min(key, len - 1);
+    const bf16_t* kr = base + E + (size_t)ki * 3 * E + 8 * g;
+    const bf16x8 kb0 = a3_ld16(kr), kb1 = a3_ld16(kr + 16), vb0 = a3_ld16(kr + E), vb1 = a3_ld16(kr + E + 16);
+    const float scale = rsqrtf(32.0f);
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    f32x16 dK, dV;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dK[r] = 0.0f; dV[r] = 0.0f; }
+    const int nb = LR >> 5;
+    for (int qb = 0; qb < nb; ++qb) {
+        const int qi = min(qb * 32 + c, len - 1);
+        const bf16_t* qr = base + (size_t)qi * 3 * E + 8 * g;
+        const bf16_t* gr = gbase + (size_t)qi * E + 8 * g;
+        f32x16 S, dP;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = 0.0f; dP[r] = 0.0f; }
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(qr), kb0, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(qr + 16), kb1, S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(gr), vb0, dP, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(gr + 16), vb1, dP, 0, 0, 0);
+        float pm[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = qb * 32 + a3_idx(r, g);  // < LR: the staged arrays are padded
+            const bool ok = qq < len && key < len;
+            const float pv = ok ? __expf(S[r] * scale - lse_s[qq]) : 0.0f;
+            const float msk = p_drop > 0.0f ? dropout_scale(rk_s[qq], (unsigned)key, p_drop, inv_keep) : 1.0f;
+            pm[r] = pv * msk;
+            ds[r] = pv * (dP[r] * msk - del_s[qq]) * scale;
+        }
+        const bf16_t* gt = Gt + (size_t)c * LP + qb * 32 + 4 * g;
+        const bf16_t* qt = Qt + (size_t)c * LP + qb * 32 + 4 * g;
+        dV = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_pack(pm, 0), a3_ldt(gt), dV, 0, 0, 0);
+        dV = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_pack(pm, 1), a3_ldt(gt + 16), dV, 0, 0, 0);
+        dK = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_pack(ds, 0), a3_ldt(qt), dK, 0, 0, 0);
+        dK = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_pack(ds, 1), a3_ldt(qt + 16), dK, 0, 0, 0);
+    }
+    // accumulators: lane = head-dim column c, register r <-> key k0 + idx(r, g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int kk = k0 + a3_idx(r, g);
+        if (kk < len) {
+            bf16_t* o = dqkv + ((size_t)s * len + kk) * 3 * E + E + h * 32 + c;
+            o[0] = f2bf(dK[r]);
+            o[E] = f2bf(dV[r]);
+        }
+    }
+}
+
+inline bool attn3_ok(int len, int heads, int hd, int dtype, const void* a, const void* b, const void* c) {
+    if (dtype != SPV_BF16 || hd != 32 || len < 2 || (heads * hd) % 8) return false;
+    if (((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)c & 15)) return false;
+    const size_t LP = ((len + 31) & ~31) + 4;
+    return 2 * 32 * LP * 2 + 3 * (LP - 4) * 4 <= 150 * 1024;
+}
+
 int check(const char* name, int seqs, int len, int heads, int hd, int dtype) {
     SPV_CHECK(seqs > 0 && len > 0 && heads > 0 && hd > 0, "%s: empty", name);
     SPV_CHECK(len <= 64 * MAXC, "%s: len=%d > %d", name, len, 64 * MAXC);
@@ -520,6 +820,15 @@ int check(const char* name, int seqs, int len, int heads, int hd, int dtype) {
 extern "C" int spv_attention_fwd(const void* qkv, void* ctx, void* probs, int seqs, int len, int heads, int head_dim, int dtype,
                                  float p_drop, uint64_t seed, void* stream) {
     if (check("spv_attention_fwd", seqs, len, heads, head_dim, dtype)) return 1;
+    if (attn3_ok(len, heads, head_dim, dtype, qkv, ctx, probs)) {
+        const int LP = ((len + 31) & ~31) + 4;
+        const size_t lds = (size_t)32 * LP * 2;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attn3_fwd_kernel<false>), dim3(seqs * heads, cdiv(len, 128)), dim3(256), lds, static_cast<hipStream_t>(stream),
+                           (const bf16_t*)qkv, (bf16_t*)ctx, (bf16_t*)nullptr, (float*)probs, len, heads, p_drop, seed);
+        SPV_LAUNCH_CHECK("spv_attention_fwd(v3)");
+        return 0;
+    }
     if (dtype == SPV_BF16 && attn2_ok<bf16_t>(len, heads, head_dim, qkv, ctx))
         A2_DISPATCH(bf16_t, head_dim, launch_attn2_fwd, qkv, ctx, probs, seqs, len, heads, p_drop, seed, static_cast<hipStream_t>(stream));
     if (dtype == SPV_F32 && attn2_ok<float>(len, heads, head_dim, qkv, ctx))
@@ -535,6 +844,20 @@ extern "C" int spv_attention_bwd(const void* dctx, const void* qkv, const void* 
                                  int heads, int head_dim, int dtype, float p_drop, uint64_t seed, void* stream) {
     if (check("spv_attention_bwd", seqs, len, heads, head_dim, dtype)) return 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (attn3_ok(len, heads, head_dim, dtype, qkv, dctx, probs) && ((uintptr_t)dscores & 15) == 0) {
+        const int LR = (len + 31) & ~31, LP = LR + 4;
+        const size_t lds_q = (size_t)32 * LP * 2, lds_kv = (size_t)2 * 32 * LP * 2 + (size_t)3 * LR * 4;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        dim3 grid(seqs * heads, cdiv(len, 128));
+        hipLaunchKernelGGL(attn3_bwd_q_kernel, grid, dim3(256), lds_q, st, (const bf16_t*)dctx, (const bf16_t*)qkv, (const float*)probs,
+                           (float*)dscores, (bf16_t*)dqkv, len, heads, p_drop, seed);
+        SPV_LAUNCH_CHECK("spv_attention_bwd(v3 q)");
+        hipLaunchKernelGGL(attn3_bwd_kv_kernel, grid, dim3(256), lds_kv, st, (const bf16_t*)dctx, (const bf16_t*)qkv, (const float*)probs,
+                           (const float*)dscores, (bf16_t*)dqkv, len, heads, p_drop, seed);
+        SPV_LAUNCH_CHECK("spv_attention_bwd(v3 kv)");
+        return 0;
+    }
     if (dtype == SPV_BF16 && attn2_ok<bf16_t>(len, heads, head_dim, qkv, dctx))
         A2_DISPATCH(bf16_t, head_dim, launch_attn2_bwd, dctx, qkv, probs, dscores, dqkv, seqs, len, heads, p_drop, seed, st);
     if (dtype == SPV_F32 && attn2_ok<float>(len, heads, head_dim, qkv, dctx))
