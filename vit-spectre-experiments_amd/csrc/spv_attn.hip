@@ -577,14 +577,17 @@ __global__ __launch_bounds__(256) void attn3_fwd_kernel(const bf16_t* __restrict
     const float scale = rsqrtf(32.0f);
     const int nb = LR >> 5;
     float m = -INFINITY, l = 0.0f;
+    // the K rows of block kb + 1 are requested before block kb is used: the loop is otherwise one global round trip per block
+    auto krow = [&](int kb) { return base + E + (size_t)min(kb * 32 + c, len - 1) * 3 * E + 8 * g; };
+    bf16x8 nk0 = a3_ld16(krow(0)), nk1 = a3_ld16(krow(0) + 16);
     for (int kb = 0; kb < nb; ++kb) {
-        const int ki = min(kb * 32 + c, len - 1);
-        const bf16_t* kr = base + E + (size_t)ki * 3 * E + 8 * g;
+        const bf16x8 ka0 = nk0, ka1 = nk1;
+        if (kb + 1 < nb) { nk0 = a3_ld16(krow(kb + 1)); nk1 = a3_ld16(krow(kb + 1) + 16); }
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.0f;
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr), qb0, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr + 16), qb1, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qb0, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qb1, S, 0, 0, 0);
         float bm = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -613,14 +616,16 @@ __global__ __launch_bounds__(256) void attn3_fwd_kernel(const bf16_t* __restrict
     f32x16 O;
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[r] = 0.0f;
+    nk0 = a3_ld16(krow(0));
+    nk1 = a3_ld16(krow(0) + 16);
     for (int kb = 0; kb < nb; ++kb) {
-        const int ki = min(kb * 32 + c, len - 1);
-        const bf16_t* kr = base + E + (size_t)ki * 3 * E + 8 * g;
+        const bf16x8 ka0 = nk0, ka1 = nk1;
+        if (kb + 1 < nb) { nk0 = a3_ld16(krow(kb + 1)); nk1 = a3_ld16(krow(kb + 1) + 16); }
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.0f;
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr), qb0, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr + 16), qb1, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qb0, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qb1, S, 0, 0, 0);
         float pv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -681,17 +686,22 @@ __global__ __launch_bounds__(256) void attn3_bwd_q_kernel(const bf16_t* __restri
     f32x16 dQ;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dQ[r] = 0.0f;
+    auto krow = [&](int kb) { return base + E + (size_t)min(kb * 32 + c, len - 1) * 3 * E + 8 * g; };
     for (int pass = 0; pass < 2; ++pass) {
+        bf16x8 nk0 = a3_ld16(krow(0)), nk1 = a3_ld16(krow(0) + 16), nv0 = a3_ld16(krow(0) + E), nv1 = a3_ld16(krow(0) + E + 16);
         for (int kb = 0; kb < nb; ++kb) {
-            const int ki = min(kb * 32 + c, len - 1);
-            const bf16_t* kr = base + E + (size_t)ki * 3 * E + 8 * g;
+            const bf16x8 ka0 = nk0, ka1 = nk1, va0 = nv0, va1 = nv1;  // V row = K row + E
+            if (kb + 1 < nb) {  // next block's rows in flight under this block's arithmetic
+                const bf16_t* nr = krow(kb + 1);
+                nk0 = a3_ld16(nr); nk1 = a3_ld16(nr + 16); nv0 = a3_ld16(nr + E); nv1 = a3_ld16(nr + E + 16);
+            }
             f32x16 S, dP;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { S[r] = 0.0f; dP[r] = 0.0f; }
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr), qb0, S, 0, 0, 0);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr + 16), qb1, S, 0, 0, 0);
-            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr + E), gb0, dP, 0, 0, 0);        // V row = K row + E
-            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(kr + E + 16), gb1, dP, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qb0, S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qb1, S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, gb0, dP, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, gb1, dP, 0, 0, 0);
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -760,17 +770,22 @@ __global__ __launch_bounds__(256) void attn3_bwd_kv_kernel(const bf16_t* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dK[r] = 0.0f; dV[r] = 0.0f; }
     const int nb = LR >> 5;
+    auto qrow = [&](int qb) { return base + (size_t)min(qb * 32 + c, len - 1) * 3 * E + 8 * g; };
+    auto grow = [&](int qb) { return gbase + (size_t)min(qb * 32 + c, len - 1) * E + 8 * g; };
+    bf16x8 nq0 = a3_ld16(qrow(0)), nq1 = a3_ld16(qrow(0) + 16), ng0 = a3_ld16(grow(0)), ng1 = a3_ld16(grow(0) + 16);
     for (int qb = 0; qb < nb; ++qb) {
-        const int qi = min(qb * 32 + c, len - 1);
-        const bf16_t* qr = base + (size_t)qi * 3 * E + 8 * g;
-        const bf16_t* gr = gbase + (size_t)qi * E + 8 * g;
+        const bf16x8 qa0 = nq0, qa1 = nq1, ga0 = ng0, ga1 = ng1;
+        if (qb + 1 < nb) {  // next block's Q / dctx rows in flight under this block's arithmetic
+            nq0 = a3_ld16(qrow(qb + 1)); nq1 = a3_ld16(qrow(qb + 1) + 16);
+            ng0 = a3_ld16(grow(qb + 1)); ng1 = a3_ld16(grow(qb + 1) + 16);
+        }
         f32x16 S, dP;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { S[r] = 0.0f; dP[r] = 0.0f; }
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(qr), kb0, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(qr + 16), kb1, S, 0, 0, 0);
-        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(gr), vb0, dP, 0, 0, 0);
-        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ld16(gr + 16), vb1, dP, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, kb0, S, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, kb1, S, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga0, vb0, dP, 0, 0, 0);
+        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga1, vb1, dP, 0, 0, 0);
         float pm[16], ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
