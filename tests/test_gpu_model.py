@@ -208,6 +208,37 @@ def test_attention_core_vs_oracle(dtype, seqs, length, heads, hd):
     check(X.grad, dqkv, tol * 2, "dqkv")
 
 
+@pytest.mark.parametrize("seqs,length,heads,hd", [(2, 130, 2, 32), (1, 512, 4, 32), (2, 65, 4, 16)])
+def test_attention_dropout_masks_agree_across_kernels(seqs, length, heads, hd):
+    """The attention-probability dropout mask is a pure function of (seed, row, key): the fp32 kernels (VALU, probabilities
+    stored) and the bf16 kernels (MFMA flash kernels for head dim 32, recomputing P in the backward) must therefore produce
+    the same masked result for the same seed, forward and backward, and <dctx, ctx> = <dV, V> (ctx is linear in V under a
+    fixed mask) ties the forward mask to the one the dK/dV kernel regenerates."""
+    from spectre_vit import hip_ops
+    rng = np.random.default_rng(11)
+    E = heads * hd
+    qkv = rng.standard_normal((seqs, length, 3 * E))
+    dctx = rng.standard_normal((seqs, length, E))
+    out = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        torch.manual_seed(1234)  # hip_ops draws the kernel seed from torch's CPU generator
+        X = t(qkv, dtype).requires_grad_(True)
+        Y = hip_ops.AttentionFn.apply(X, heads, 0.3)
+        Y.backward(t(dctx, dtype))
+        out[dtype] = (n64(Y), n64(X.grad), n64(X.detach()))
+        v = out[dtype][2][..., 2 * E:]
+        dv = out[dtype][1][..., 2 * E:]
+        lhs, rhs = float((n64(t(dctx, dtype)) * out[dtype][0]).sum()), float((dv * v).sum())
+        assert abs(lhs - rhs) <= (1e-4 if dtype == torch.float32 else 3e-2) * max(1.0, abs(lhs)), (dtype, lhs, rhs)
+    rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+    assert rel(out[torch.bfloat16][0], out[torch.float32][0]) <= 3e-2, "ctx bf16 vs fp32, same mask"
+    assert rel(out[torch.bfloat16][1], out[torch.float32][1]) <= 6e-2, "dqkv bf16 vs fp32, same mask"
+    # and the mask really drops something
+    torch.manual_seed(1234)
+    Y0 = hip_ops.AttentionFn.apply(t(qkv, torch.float32), heads, 0.0)
+    assert rel(n64(Y0), out[torch.float32][0]) > 1e-2
+
+
 def test_vit_golden_forward_and_layer_backward(golden_ops):
     """the reference's own ViT forward (batch-axis attention quirk) and TransformerEncoderLayer backward, fp32"""
     from spectre_vit.models.vit.vit import ViT, _encoder_layer_forward
