@@ -113,11 +113,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    # SPV_BENCH_REHEARSAL=1: all ranks on device 0 over gloo -- lets the multi-rank control flow (collectives, barriers,
+    # rank-0-only sections) be exercised on a one-GPU box; never used for reported numbers
+    rehearsal = os.environ.get("SPV_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     torch.manual_seed(42)
     if args.model == "vit":
@@ -165,10 +173,13 @@ def main():
     # roofline pass: the same step, same process, right after the timed region, with HIP events recorded on the launch
     # stream around every GEMM / FNet-mixer launch.  Kept out of the headline timing because the ~60 event pairs per
     # step perturb it (measured: 6.3 ms/step bracketed vs 4.9 ms/step clean).
+    # Every rank runs these steps (each one contains the gradient all-reduce: a rank that skipped them would leave the
+    # others waiting in the collective); only rank 0 records events.
     timer = None
-    if not args.no_roofline and rank == 0:
-        timer = hip_ops.KernelTimer()
-        hip_ops.set_kernel_timer(timer)
+    if not args.no_roofline:
+        if rank == 0:
+            timer = hip_ops.KernelTimer()
+            hip_ops.set_kernel_timer(timer)
         for _ in range(min(args.steps, 20)):
             step()
         torch.cuda.synchronize()
@@ -202,6 +213,7 @@ def main():
                                     if args.model == "spectre" else
                                     "baseline ViT-Small (E512 H16 F768 L4 P4 N65, MHSA with the reference's batch_first=False axis), ")
                                    + f"train step fwd+CE+bwd+AdamW, bs {args.batch}/GPU",
+                       **({"rehearsal": "all ranks on one device over gloo: control-flow check, not a measurement"} if rehearsal else {}),
                        "mixer": args.mixer if args.model == "spectre" else "attention", "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "final_loss": round(final_loss, 4),
         }

@@ -83,3 +83,23 @@ def test_two_ranks_on_one_gpu(mixer, tmp_path):
         ref = p.grad.cpu()
         err = (r0["grads"][k] - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
         assert err < 2e-4, (k, err)
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_control_flow(tmp_path):
+    """bench.py with 2 ranks (both on device 0, gloo): every collective is entered by every rank -- in particular the
+    roofline pass after the timed region, whose steps contain the gradient all-reduce -- and rank 0 prints one JSON line."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SPV_BENCH_REHEARSAL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "64"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 128
+    assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec
