@@ -619,19 +619,27 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
         const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
         float o[CO];
 #pragma unroll
-        for (int c = 0; c < CO; ++c) {
-            constexpr int dummy = 0; (void)dummy;
-            float acc = 0.0f;
+        for (int c = 0; c < CO; c += 2) {  // column pairs: packed fp32 math
+            float pv[2];
 #pragma unroll
-            for (int j = 0; j < CI; ++j)
-                if (j >= lc_ws(c, CO, CI) && j < lc_we(c, CO, CI)) acc += xin[j];
-            const float pv = acc * (1.0f / (float)(lc_we(c, CO, CI) - lc_ws(c, CO, CI)));
-            const float ln = (hv[c] - mean) * rstd * g[c] + b[c];
-            float act, unused;
-            if (FASTG) gelu_fast(ln, act, unused);
-            else act = gelu_erf(ln);
-            o[c] = act + pv;
-            if (p_drop > 0.0f) o[c] *= dropout_scale(rkey, (unsigned)(lane * CO + c), p_drop, inv_keep);
+            for (int u = 0; u < 2; ++u) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < CI; ++j)
+                    if (j >= lc_ws(c + u, CO, CI) && j < lc_we(c + u, CO, CI)) acc += xin[j];
+                pv[u] = acc * (1.0f / (float)(lc_we(c + u, CO, CI) - lc_ws(c + u, CO, CI)));
+            }
+            const f32x2 hv2 = {hv[c], hv[c + 1]}, g2 = {g[c], g[c + 1]}, b2 = {b[c], b[c + 1]};
+            const f32x2 ln = (hv2 - mean) * (g2 * rstd) + b2;
+            f32x2 act, unused;
+            if (FASTG) gelu_fast2(ln, act, unused);
+            else act = f32x2{gelu_erf(ln.x), gelu_erf(ln.y)};
+            o[c] = act.x + pv[0];
+            o[c + 1] = act.y + pv[1];
+            if (p_drop > 0.0f) {
+                o[c] *= dropout_scale(rkey, (unsigned)(lane * CO + c), p_drop, inv_keep);
+                o[c + 1] *= dropout_scale(rkey, (unsigned)(lane * CO + c + 1), p_drop, inv_keep);
+            }
         }
         st_span<CO>(out, (size_t)row * n + lane * CO, out_bf, o);
         if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
