@@ -174,6 +174,38 @@ def test_spectre_linear_dropout(ops):
     assert torch.isfinite(gx).all()
 
 
+@pytest.mark.parametrize("n,k", [(768, 512), (512, 768)])
+def test_spectre_linear_small_p_dropout_statistics(ops, n, k):
+    """Small p on the 512 <-> 768 layer shapes (lane-contiguous row kernels): the counter-hash mask must be i.i.d.
+    Bernoulli(p) -- rate, per-row count variance (a scheme with 'at most one drop per group' would show a deficit), column
+    coverage, kept values -- and the backward must regenerate the same mask."""
+    torch.manual_seed(3)
+    rows, p = 4096, 0.004
+    X = torch.randn(rows, k, device=dev()).requires_grad_(True)
+    W = (torch.randn(n, k, device=dev()) / 16).requires_grad_(True)
+    b = torch.zeros(n, device=dev(), requires_grad=True)
+    g = torch.ones(n, device=dev(), requires_grad=True)
+    be = torch.full((n,), 0.3, device=dev(), requires_grad=True)
+    y0 = ops.spectre_linear(X, W, b, g, be, 0.0, False).detach()
+    y1 = ops.spectre_linear(X, W, b, g, be, p, False)
+    live = y0 != 0
+    dropped = (y1 == 0) & live
+    frac = dropped.float().sum().item() / live.float().sum().item()
+    assert abs(frac - p) < 3e-4, frac
+    cnt = dropped.float().sum(1)
+    assert abs(cnt.mean().item() - n * p) < 0.15 and abs(cnt.var().item() / (n * p * (1 - p)) - 1.0) < 0.12, (cnt.mean().item(), cnt.var().item())
+    col = dropped.float().sum(0)
+    assert col.min().item() >= 1 and col.max().item() <= 50, (col.min().item(), col.max().item())
+    kept = live & ~dropped
+    torch.testing.assert_close(y1.detach()[kept], (y0 / (1 - p))[kept], rtol=1e-5, atol=1e-6)
+    y1.sum().backward()
+    gx1 = X.grad.clone()
+    X.grad = None
+    y2 = ops.spectre_linear(X, W, b, g, be, 0.0, False)
+    y2.backward((~dropped).float() / (1 - p))  # the same mask applied through the output gradient
+    torch.testing.assert_close(gx1, X.grad, rtol=2e-4, atol=2e-5)
+
+
 # ------------------------------------------------------------------------------------------------ add + LayerNorm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("mode", [0, 1])
