@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""NT GEMM check + timing at the layer shapes (development tool).  Env SPV_GEMM_WIDE / SPV_GEMM_KB select kernels.
+"""NT GEMM check + timing at the layer shapes (development tool).  Env SPV_GEMM_KB forces the direct-to-LDS kernel (tile-shape variants live in tools/gemm_lab.hip).
 
     python tools/gemm_check.py [M N K ...]
 """
@@ -39,7 +39,7 @@ def run(M, N, K, acc=0, iters=30):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     print(f"gemm {M}x{N}x{K} acc={acc}: rel err {err:.2e}  {us:8.2f} us  {2.0 * M * N * K / us * 1e-6:7.1f} TFLOP/s "
-          f"[WIDE={os.environ.get('SPV_GEMM_WIDE', '0')} KB={os.environ.get('SPV_GEMM_KB', '-')}]", flush=True)
+          f"[KB={os.environ.get('SPV_GEMM_KB', '-')}]", flush=True)
     assert err < 2e-2, err
 
 

@@ -405,109 +405,6 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// NT contraction, wide-tile direct-to-LDS variant for the big-M layer GEMMs (bf16): 256 x 128 tile, 4 waves as 2 x 2,
-// each wave a 128 x 64 block (8 MFMA 32x32 accumulators = 128 AGPRs).  Why: a 128 x 128 tile moves 1 operand byte
-// through the CU's vector-memory path (64 B/clk) per 64 flops -- exactly the ratio at which that path, not the MFMA,
-// is the ceiling -- and re-reads every LDS byte 2x; 256 x 128 needs 85 flops per loaded byte and 1.5 LDS reads per
-// MFMA instead of 2.  K is staged 64 bytes (32 elements) per row per stage, NST stages in flight (prefetch distance
-// NST-1), one barrier per stage; rows are 64 B so a wave DMA instruction covers 16 tile rows, and the 16-byte chunk
-// index is XOR-ed with (row >> 2) & 3 (16 consecutive rows x 4 chunks = all 64 banks for a ds_read_b128 lane group).
-template <typename TO, int NST>
-__global__ __launch_bounds__(256) void gemm_nt_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                           const float* __restrict__ bias, TO* __restrict__ C,
-                                                           float* __restrict__ ws, int M, int N, int K, int lda, int ldb,
-                                                           int ldc, int k_per_split, int accumulate, int tiles_n,
-                                                           int tiles_mn, int nsplit, const void* __restrict__ bc, int bc_pw,
-                                                           int bc_bf) {
-    constexpr int WBM = 256, KB = 64, KE = KB / 2;
-    constexpr int STAGE = (WBM + BN) * KB;  // 24 KiB
-    constexpr int IPA = WBM / 16 / 4, IPB = BN / 16 / 4;  // DMA instructions per wave per stage: 4 (A) + 2 (B)
-    constexpr int SM = NST * STAGE > 36864 ? NST * STAGE : 36864;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[SM];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);
-    const int split = lin / tiles_mn;
-    const int tile = lin % tiles_mn;
-    int tm, tn;
-    tile_coords(tile, tiles_n, tiles_mn, tm, tn);
-    const int m0 = tm * WBM, n0 = tn * BN;
-    const int kbeg = split * k_per_split;
-    const int kend = min(K, kbeg + k_per_split);
-
-    const bf16_t* asrc[IPA];
-    const bf16_t* bsrc[IPB];
-#pragma unroll
-    for (int t = 0; t < IPA; ++t) {
-        const int R = 16 * (wave * IPA + t) + (lane >> 2);
-        const int c = (lane & 3) ^ ((R >> 2) & 3);
-        asrc[t] = A + (size_t)min(m0 + R, M - 1) * lda + c * 8;
-    }
-#pragma unroll
-    for (int t = 0; t < IPB; ++t) {
-        const int R = 16 * (wave * IPB + t) + (lane >> 2);
-        const int c = (lane & 3) ^ ((R >> 2) & 3);
-        bsrc[t] = B + (size_t)min(n0 + R, N - 1) * ldb + c * 8;
-    }
-    auto stage = [&](int buf, int k0) {
-        unsigned char* sa = smem + buf * STAGE + wave * IPA * 1024;
-        unsigned char* sb = smem + buf * STAGE + WBM * KB + wave * IPB * 1024;
-#pragma unroll
-        for (int t = 0; t < IPA; ++t)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[t] + k0),
-                                             (__attribute__((address_space(3))) void*)(sa + t * 1024), 16, 0, 0);
-#pragma unroll
-        for (int t = 0; t < IPB; ++t)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[t] + k0),
-                                             (__attribute__((address_space(3))) void*)(sb + t * 1024), 16, 0, 0);
-    };
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 2) & 3;  // 32-row offsets do not change the swizzle
-    const int fa_off = (wm * 128 + frow) * KB, fb_off = WBM * KB + (wn * 64 + frow) * KB;
-
-    const int nk = (kend - kbeg + KE - 1) / KE;
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (s < nk) stage(s, kbeg + s * KE);
-    int buf = 0;
-    for (int t = 0; t < nk; ++t) {
-        // stages t .. min(t + NST - 2, nk - 1) are in flight; wait for stage t only
-        const int ahead = min(NST - 2, nk - 1 - t);
-        if (NST >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((IPA + IPB) * 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // stage t landed for everyone; everyone finished reading stage t - 1
-        if (t + NST - 1 < nk) stage((buf + NST - 1) % NST, kbeg + (t + NST - 1) * KE);
-        const unsigned char* sa = smem + buf * STAGE + fa_off;
-        const unsigned char* sb = smem + buf * STAGE + fb_off;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int ch = ((ks * 2 + fh) ^ swz) * 16;
-            bf16x8 a[4], b[2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f) b[f] = *reinterpret_cast<const bf16x8*>(sb + f * 32 * KB + ch);
-#pragma unroll
-            for (int f = 0; f < 4; ++f) a[f] = *reinterpret_cast<const bf16x8*>(sa + f * 32 * KB + ch);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        buf = (buf + 1 == NST) ? 0 : buf + 1;
-    }
-    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr, bc, bc_pw, bc_bf, wm * 128);
-    store_acc_tile<TO>(acc + 2, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr, bc, bc_pw, bc_bf, wm * 128 + 64);
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // TN contraction: C[M,N] = sum_k A[k][m] * B[k][n]  with A [K, lda>=M] and B [K, ldb>=N] row-major (bf16).
 // This is the weight gradient dW = dh^T . x taken straight from the row-major activations: no transposed copies.
 // Tiles are staged in LDS exactly as they lie in memory ([k][m] rows of 256 B + 64 B pad, coalesced 16-byte loads);
@@ -641,21 +538,6 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
     float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
     dim3 grid(tiles_m * tiles_n * splits);
     if constexpr (sizeof(T) == 2) {
-        static const int wide = getenv("SPV_GEMM_WIDE") ? atoi(getenv("SPV_GEMM_WIDE")) : 0;  // tuning aid: stages
-        if (wide && rg == 0 && M >= 4096 && K % 32 == 0 && k_per_split % 32 == 0) {
-            const int wtm = cdiv(M, 256);
-            dim3 wgrid(wtm * tiles_n * splits);
-            if (wide == 2)
-                hipLaunchKernelGGL((gemm_nt_wide_kernel<TO, 2>), wgrid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
-                                   static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                                   accumulate, tiles_n, wtm * tiles_n, splits, bc, bc_pw, bc_bf);
-            else
-                hipLaunchKernelGGL((gemm_nt_wide_kernel<TO, 3>), wgrid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
-                                   static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                                   accumulate, tiles_n, wtm * tiles_n, splits, bc, bc_pw, bc_bf);
-            SPV_LAUNCH_CHECK("spv_gemm_nt(wide)");
-            goto reduce;
-        }
         // direct-to-LDS double-buffered kernel for long reductions (measured: 896 vs 795 TFLOP/s at 4096^3, 755 vs 700 on
         // the 512 x 8192 x 33280 weight gradient); the skinny K <= 1024 layer GEMMs are faster on the register-staged
         // kernel (42 vs 50 us at 33280 x 768 x 512: three workgroups per CU instead of two)
