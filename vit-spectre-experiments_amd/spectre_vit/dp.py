@@ -4,7 +4,7 @@ The reference is single-process (spectre_vit/repl/train.py:41); the step shards 
 op mixes samples, so the only exchange is one gradient all-reduce per step.  One process per GPU,
 ``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm); gloo on CPU for the tests.
 
-GradReducer lays a few large flat fp32 buckets out in reverse registration order (~ the order backward produces the
+GradReducer lays a few flat fp32 buckets (8 MB, the last-completing one 2 MB) out in reverse registration order (~ the order backward produces the
 gradients: head -> last layer -> ... -> embedding) and hands every parameter its slot as a ``GradSink``: the HIP backward
 kernels write dW / db / dgamma ... directly into the bucket, autograd adopts that view as ``p.grad`` (no extra
 ``grad += new`` pass).  A post-accumulate hook (which also stages gradients that arrived from other ops) counts a
@@ -21,7 +21,8 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, module: torch.nn.Module, bucket_mb: float = 8.0, process_group=None, reduce_dtype=None):
+    def __init__(self, module: torch.nn.Module, bucket_mb: float = 8.0, process_group=None, reduce_dtype=None,
+                 tail_mb: float = 2.0):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -37,9 +38,18 @@ class GradReducer:
         except Exception:  # the reducer itself is model agnostic (CPU gloo tests use a stock model)
             GradSink = None
         cap = int(bucket_mb * 1024 * 1024 / 4)
+        # The bucket that completes LAST (the first-registered parameters: embedding, first layer) has nothing left to hide
+        # behind, so it is kept small: its all-reduce is the exposed tail of the step.
+        tail_cap = int(min(tail_mb, bucket_mb) * 1024 * 1024 / 4)
+        tail, tail_n = [], 0
+        for p in self.params:
+            if tail and tail_n + p.numel() > tail_cap:
+                break
+            tail.append(p)
+            tail_n += p.numel()
         cur, cur_n = [], 0
         groups = []
-        for p in reversed(self.params):
+        for p in reversed(self.params[len(tail):]):
             if cur and cur_n + p.numel() > cap:
                 groups.append(cur)
                 cur, cur_n = [], 0
@@ -47,6 +57,7 @@ class GradReducer:
             cur_n += p.numel()
         if cur:
             groups.append(cur)
+        groups.append(list(reversed(tail)))
         for bi, ps in enumerate(groups):
             n = sum(p.numel() for p in ps)
             flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
