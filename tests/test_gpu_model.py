@@ -181,7 +181,7 @@ def test_state_dict_roundtrip_and_deepcopy():
 # ------------------------------------------------------------------------------------------------ baseline ViT
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("seqs,length,heads,hd", [(5, 7, 4, 4), (3, 130, 2, 32), (2, 512, 16, 32), (4, 65, 4, 16), (3, 197, 3, 64),
-                                                  (2, 65, 16, 32), (1, 1, 2, 32)])
+                                                  (2, 65, 16, 32), (1, 1, 2, 32), (2, 256, 3, 64)])
 def test_attention_core_vs_oracle(dtype, seqs, length, heads, hd):
     from spectre_vit import hip_ops
     rng = np.random.default_rng(seqs * 100 + length)
@@ -208,7 +208,7 @@ def test_attention_core_vs_oracle(dtype, seqs, length, heads, hd):
     check(X.grad, dqkv, tol * 2, "dqkv")
 
 
-@pytest.mark.parametrize("seqs,length,heads,hd", [(2, 130, 2, 32), (1, 512, 4, 32), (2, 65, 4, 16)])
+@pytest.mark.parametrize("seqs,length,heads,hd", [(2, 130, 2, 32), (1, 512, 4, 32), (2, 65, 4, 16), (2, 197, 3, 64)])
 def test_attention_dropout_masks_agree_across_kernels(seqs, length, heads, hd):
     """The attention-probability dropout mask is a pure function of (seed, row, key): the fp32 kernels (VALU, probabilities
     stored) and the bf16 kernels (MFMA flash kernels for head dim 32, recomputing P in the backward) must therefore produce

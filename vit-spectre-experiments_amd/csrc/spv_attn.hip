@@ -508,7 +508,7 @@ template <typename T> inline bool attn2_ok(int len, int heads, int hd, const voi
     } while (0)
 
 // ------------------------------------------------------------------------------------------------------------------
-// v3 (bf16, head_dim 32): both contractions on MFMA, nothing of size len x len stored.
+// v3 (bf16, head_dim 32 or 64): both contractions on MFMA, nothing of size len x len stored.
 //
 // A wave owns 32 queries (forward, backward-1) or 32 keys (backward-2) and walks the other axis in blocks of 32.  The
 // score block is computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_bf16, 2 per block), so a lane owns one query
@@ -540,11 +540,13 @@ __device__ __forceinline__ bf16x8 a3_pack(const float (&v)[16], int t) {
     for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(v[8 * t + j]);
     return __builtin_bit_cast(bf16x8, o);
 }
-// stage src rows [len][32] (row stride gstride elements) transposed into dst[32][LP], zero beyond len (LR = LP - 4 columns)
+// stage src rows [len][HD] (row stride gstride elements) transposed into dst[HD][LP], zero beyond len (LR = LP - 4 columns)
+template <int HD>
 __device__ __forceinline__ void a3_stage_t(const bf16_t* __restrict__ src, size_t gstride, bf16_t* dst, int len, int LP) {
+    constexpr int CPR = HD / 8;  // 16-byte chunks per row
     const int LR = LP - 4;
-    for (int e = threadIdx.x; e < LR * 4; e += blockDim.x) {
-        const int key = e >> 2, c = e & 3;
+    for (int e = threadIdx.x; e < LR * CPR; e += blockDim.x) {
+        const int key = e / CPR, c = e % CPR;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (key < len) v = *reinterpret_cast<const uint4*>(src + (size_t)key * gstride + c * 8);
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
@@ -558,36 +560,61 @@ __device__ __forceinline__ void a3_stage_t(const bf16_t* __restrict__ src, size_
 // entry index inside a 32-block of accumulator register r for lane half g
 __device__ __forceinline__ int a3_idx(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
-template <bool WRITE_P>
-__global__ __launch_bounds__(256) void attn3_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                        bf16_t* __restrict__ probs, float* __restrict__ lse, int len, int heads,
-                                                        float p_drop, uint64_t seed) {
+__device__ __forceinline__ f32x16 a3_zero() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return z;
+}
+// write one lane's 16 accumulator entries (4 runs of 4 consecutive columns) of a 32-wide block as 8-byte stores
+__device__ __forceinline__ void a3_store_block(bf16_t* o, const f32x16& v) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+        uint2 w;
+        w.x = (unsigned)f2bf(v[4 * qd]) | ((unsigned)f2bf(v[4 * qd + 1]) << 16);
+        w.y = (unsigned)f2bf(v[4 * qd + 2]) | ((unsigned)f2bf(v[4 * qd + 3]) << 16);
+        *reinterpret_cast<uint2*>(o + 8 * qd) = w;
+    }
+}
+
+// HD = head dim (32 or 64): KS = HD / 16 MFMA k steps for the score products, DB = HD / 32 output blocks of the second products
+template <int HD>
+__global__ __launch_bounds__(256, (HD == 32 ? 4 : 3)) void attn3_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx, float* __restrict__ lse,
+                                                        int len, int heads, float p_drop, uint64_t seed) {
+    constexpr int KS = HD / 16, DB = HD / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     bf16_t* Vt = reinterpret_cast<bf16_t*>(lds3);
     const int LR = (len + 31) & ~31, LP = LR + 4;
-    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * 32;
-    const bf16_t* base = qkv + (size_t)s * len * 3 * E + h * 32;
-    a3_stage_t(base + 2 * E, (size_t)3 * E, Vt, len, LP);
+    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * HD;
+    const bf16_t* base = qkv + (size_t)s * len * 3 * E + h * HD;
+    a3_stage_t<HD>(base + 2 * E, (size_t)3 * E, Vt, len, LP);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, c = lane & 31;
     const int q0 = (blockIdx.y * 4 + wave) * 32;
     if (q0 >= len) return;
     const int q = q0 + c, qi = min(q, len - 1);
-    const bf16x8 qb0 = a3_ld16(base + (size_t)qi * 3 * E + 8 * g), qb1 = a3_ld16(base + (size_t)qi * 3 * E + 16 + 8 * g);
-    const float scale = rsqrtf(32.0f);
+    bf16x8 qb[KS];
+#pragma unroll
+    for (int t = 0; t < KS; ++t) qb[t] = a3_ld16(base + (size_t)qi * 3 * E + 16 * t + 8 * g);
+    const float scale = rsqrtf((float)HD);
     const int nb = LR >> 5;
     float m = -INFINITY, l = 0.0f;
     // the K rows of block kb + 1 are requested before block kb is used: the loop is otherwise one global round trip per block
     auto krow = [&](int kb) { return base + E + (size_t)min(kb * 32 + c, len - 1) * 3 * E + 8 * g; };
-    bf16x8 nk0 = a3_ld16(krow(0)), nk1 = a3_ld16(krow(0) + 16);
-    for (int kb = 0; kb < nb; ++kb) {
-        const bf16x8 ka0 = nk0, ka1 = nk1;
-        if (kb + 1 < nb) { nk0 = a3_ld16(krow(kb + 1)); nk1 = a3_ld16(krow(kb + 1) + 16); }
-        f32x16 S;
+    bf16x8 nk[KS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qb0, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qb1, S, 0, 0, 0);
+    for (int t = 0; t < KS; ++t) nk[t] = a3_ld16(krow(0) + 16 * t);
+    for (int kb = 0; kb < nb; ++kb) {
+        bf16x8 ka[KS];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) ka[t] = nk[t];
+        if (kb + 1 < nb) {
+#pragma unroll
+            for (int t = 0; t < KS; ++t) nk[t] = a3_ld16(krow(kb + 1) + 16 * t);
+        }
+        f32x16 S = a3_zero();
+#pragma unroll
+        for (int t = 0; t < KS; ++t) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[t], qb[t], S, 0, 0, 0);
         float bm = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -613,95 +640,99 @@ __global__ __launch_bounds__(256) void attn3_fwd_kernel(const bf16_t* __restrict
     if (g == 0 && q < len) lse[(size_t)sh * len + q] = m + __logf(l);
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
     const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, qi)) : 0u;
-    f32x16 O;
+    f32x16 O[DB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) O[r] = 0.0f;
-    nk0 = a3_ld16(krow(0));
-    nk1 = a3_ld16(krow(0) + 16);
+    for (int d = 0; d < DB; ++d) O[d] = a3_zero();
+#pragma unroll
+    for (int t = 0; t < KS; ++t) nk[t] = a3_ld16(krow(0) + 16 * t);
     for (int kb = 0; kb < nb; ++kb) {
-        const bf16x8 ka0 = nk0, ka1 = nk1;
-        if (kb + 1 < nb) { nk0 = a3_ld16(krow(kb + 1)); nk1 = a3_ld16(krow(kb + 1) + 16); }
-        f32x16 S;
+        bf16x8 ka[KS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.0f;
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qb0, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qb1, S, 0, 0, 0);
+        for (int t = 0; t < KS; ++t) ka[t] = nk[t];
+        if (kb + 1 < nb) {
+#pragma unroll
+            for (int t = 0; t < KS; ++t) nk[t] = a3_ld16(krow(kb + 1) + 16 * t);
+        }
+        f32x16 S = a3_zero();
+#pragma unroll
+        for (int t = 0; t < KS; ++t) S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[t], qb[t], S, 0, 0, 0);
         float pv[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kb * 32 + a3_idx(r, g);
             pv[r] = key < len ? __expf(S[r] * scale - m) * inv : 0.0f;
         }
-        if (WRITE_P && q < len) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb * 32 + a3_idx(r, g);
-                if (key < len) probs[((size_t)sh * len + q) * len + key] = f2bf(pv[r]);
-            }
-        }
         if (p_drop > 0.0f) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) pv[r] *= dropout_scale(rkey, (unsigned)(kb * 32 + a3_idx(r, g)), p_drop, inv_keep);
         }
-        const bf16_t* vr = Vt + (size_t)c * LP + kb * 32 + 4 * g;
-        O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(vr), a3_pack(pv, 0), O, 0, 0, 0);
-        O = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(vr + 16), a3_pack(pv, 1), O, 0, 0, 0);
+        const bf16x8 p0 = a3_pack(pv, 0), p1 = a3_pack(pv, 1);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+            const bf16_t* vr = Vt + (size_t)(d * 32 + c) * LP + kb * 32 + 4 * g;
+            O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(vr), p0, O[d], 0, 0, 0);
+            O[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(vr + 16), p1, O[d], 0, 0, 0);
+        }
     }
     if (q < len) {
-        bf16_t* o = ctx + ((size_t)s * len + q) * E + h * 32 + 4 * g;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            uint2 w;
-            w.x = (unsigned)f2bf(O[4 * qd]) | ((unsigned)f2bf(O[4 * qd + 1]) << 16);
-            w.y = (unsigned)f2bf(O[4 * qd + 2]) | ((unsigned)f2bf(O[4 * qd + 3]) << 16);
-            *reinterpret_cast<uint2*>(o + 8 * qd) = w;
-        }
+        for (int d = 0; d < DB; ++d) a3_store_block(ctx + ((size_t)s * len + q) * E + h * HD + d * 32 + 4 * g, O[d]);
     }
 }
 
 // backward 1: per wave 32 queries.  delta[q] = sum_k P dP', dS = P (dP' - delta) / sqrt(hd), dQ^T += K^T dS^T  (dP' = mask dP)
-__global__ __launch_bounds__(256) void attn3_bwd_q_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ qkv,
+template <int HD>
+__global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn3_bwd_q_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ qkv,
                                                           const float* __restrict__ lse, float* __restrict__ delta,
                                                           bf16_t* __restrict__ dqkv, int len, int heads, float p_drop, uint64_t seed) {
+    constexpr int KS = HD / 16, DB = HD / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     bf16_t* Kt = reinterpret_cast<bf16_t*>(lds3);
     const int LR = (len + 31) & ~31, LP = LR + 4;
-    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * 32;
-    const bf16_t* base = qkv + (size_t)s * len * 3 * E + h * 32;
-    a3_stage_t(base + E, (size_t)3 * E, Kt, len, LP);
+    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * HD;
+    const bf16_t* base = qkv + (size_t)s * len * 3 * E + h * HD;
+    a3_stage_t<HD>(base + E, (size_t)3 * E, Kt, len, LP);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, c = lane & 31;
     const int q0 = (blockIdx.y * 4 + wave) * 32;
     if (q0 >= len) return;
     const int q = q0 + c, qi = min(q, len - 1);
-    const bf16x8 qb0 = a3_ld16(base + (size_t)qi * 3 * E + 8 * g), qb1 = a3_ld16(base + (size_t)qi * 3 * E + 16 + 8 * g);
-    const bf16_t* gr = dctx + ((size_t)s * len + qi) * E + h * 32 + 8 * g;
-    const bf16x8 gb0 = a3_ld16(gr), gb1 = a3_ld16(gr + 16);
-    const float scale = rsqrtf(32.0f);
+    const bf16_t* gr = dctx + ((size_t)s * len + qi) * E + h * HD + 8 * g;
+    bf16x8 qb[KS], gb[KS];
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        qb[t] = a3_ld16(base + (size_t)qi * 3 * E + 16 * t + 8 * g);
+        gb[t] = a3_ld16(gr + 16 * t);
+    }
+    const float scale = rsqrtf((float)HD);
     const float lq = lse[(size_t)sh * len + qi];
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
     const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, qi)) : 0u;
     const int nb = LR >> 5;
     float dot = 0.0f;
-    f32x16 dQ;
+    f32x16 dQ[DB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dQ[r] = 0.0f;
+    for (int d = 0; d < DB; ++d) dQ[d] = a3_zero();
     auto krow = [&](int kb) { return base + E + (size_t)min(kb * 32 + c, len - 1) * 3 * E + 8 * g; };
     for (int pass = 0; pass < 2; ++pass) {
-        bf16x8 nk0 = a3_ld16(krow(0)), nk1 = a3_ld16(krow(0) + 16), nv0 = a3_ld16(krow(0) + E), nv1 = a3_ld16(krow(0) + E + 16);
+        bf16x8 nk[KS], nv[KS];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) { nk[t] = a3_ld16(krow(0) + 16 * t); nv[t] = a3_ld16(krow(0) + E + 16 * t); }  // V row = K row + E
         for (int kb = 0; kb < nb; ++kb) {
-            const bf16x8 ka0 = nk0, ka1 = nk1, va0 = nv0, va1 = nv1;  // V row = K row + E
+            bf16x8 ka[KS], va[KS];
+#pragma unroll
+            for (int t = 0; t < KS; ++t) { ka[t] = nk[t]; va[t] = nv[t]; }
             if (kb + 1 < nb) {  // next block's rows in flight under this block's arithmetic
                 const bf16_t* nr = krow(kb + 1);
-                nk0 = a3_ld16(nr); nk1 = a3_ld16(nr + 16); nv0 = a3_ld16(nr + E); nv1 = a3_ld16(nr + E + 16);
-            }
-            f32x16 S, dP;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { S[r] = 0.0f; dP[r] = 0.0f; }
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qb0, S, 0, 0, 0);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qb1, S, 0, 0, 0);
-            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, gb0, dP, 0, 0, 0);
-            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, gb1, dP, 0, 0, 0);
+                for (int t = 0; t < KS; ++t) { nk[t] = a3_ld16(nr + 16 * t); nv[t] = a3_ld16(nr + E + 16 * t); }
+            }
+            f32x16 S = a3_zero(), dP = a3_zero();
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[t], qb[t], S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[t], gb[t], dP, 0, 0, 0);
+            }
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -713,9 +744,13 @@ __global__ __launch_bounds__(256) void attn3_bwd_q_kernel(const bf16_t* __restri
                 else ds[r] = pv * (dp - dot) * scale;
             }
             if (pass == 1) {
-                const bf16_t* ktr = Kt + (size_t)c * LP + kb * 32 + 4 * g;
-                dQ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(ktr), a3_pack(ds, 0), dQ, 0, 0, 0);
-                dQ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(ktr + 16), a3_pack(ds, 1), dQ, 0, 0, 0);
+                const bf16x8 s0 = a3_pack(ds, 0), s1 = a3_pack(ds, 1);
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const bf16_t* ktr = Kt + (size_t)(d * 32 + c) * LP + kb * 32 + 4 * g;
+                    dQ[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(ktr), s0, dQ[d], 0, 0, 0);
+                    dQ[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_ldt(ktr + 16), s1, dQ[d], 0, 0, 0);
+                }
             }
         }
         if (pass == 0) {
@@ -724,33 +759,29 @@ __global__ __launch_bounds__(256) void attn3_bwd_q_kernel(const bf16_t* __restri
         }
     }
     if (q < len) {
-        bf16_t* o = dqkv + ((size_t)s * len + q) * 3 * E + h * 32 + 4 * g;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            uint2 w;
-            w.x = (unsigned)f2bf(dQ[4 * qd]) | ((unsigned)f2bf(dQ[4 * qd + 1]) << 16);
-            w.y = (unsigned)f2bf(dQ[4 * qd + 2]) | ((unsigned)f2bf(dQ[4 * qd + 3]) << 16);
-            *reinterpret_cast<uint2*>(o + 8 * qd) = w;
-        }
+        for (int d = 0; d < DB; ++d) a3_store_block(dqkv + ((size_t)s * len + q) * 3 * E + h * HD + d * 32 + 4 * g, dQ[d]);
     }
 }
 
 // backward 2: per wave 32 keys.  S = Q K^T with lane = key; dV += (mask P)^T dctx, dK += dS^T Q
-__global__ __launch_bounds__(256) void attn3_bwd_kv_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ qkv,
+template <int HD>
+__global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn3_bwd_kv_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ qkv,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16_t* __restrict__ dqkv, int len, int heads, float p_drop, uint64_t seed) {
+    constexpr int KS = HD / 16, DB = HD / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds3[];
     const int LR = (len + 31) & ~31, LP = LR + 4;
     bf16_t* Qt = reinterpret_cast<bf16_t*>(lds3);
-    bf16_t* Gt = Qt + (size_t)32 * LP;
-    float* lse_s = reinterpret_cast<float*>(Gt + (size_t)32 * LP);
+    bf16_t* Gt = Qt + (size_t)HD * LP;
+    float* lse_s = reinterpret_cast<float*>(Gt + (size_t)HD * LP);
     float* del_s = lse_s + LR;
     unsigned* rk_s = reinterpret_cast<unsigned*>(del_s + LR);
-    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * 32;
-    const bf16_t* base = qkv + (size_t)s * len * 3 * E + h * 32;
-    const bf16_t* gbase = dctx + (size_t)s * len * E + h * 32;
-    a3_stage_t(base, (size_t)3 * E, Qt, len, LP);
-    a3_stage_t(gbase, (size_t)E, Gt, len, LP);
+    const int sh = blockIdx.x, s = sh / heads, h = sh % heads, E = heads * HD;
+    const bf16_t* base = qkv + (size_t)s * len * 3 * E + h * HD;
+    const bf16_t* gbase = dctx + (size_t)s * len * E + h * HD;
+    a3_stage_t<HD>(base, (size_t)3 * E, Qt, len, LP);
+    a3_stage_t<HD>(gbase, (size_t)E, Gt, len, LP);
     for (int i = threadIdx.x; i < LR; i += blockDim.x) {
         const bool ok = i < len;
         lse_s[i] = ok ? lse[(size_t)sh * len + i] : 0.0f;
@@ -763,29 +794,34 @@ __global__ __launch_bounds__(256) void attn3_bwd_kv_kernel(const bf16_t* __restr
     if (k0 >= len) return;
     const int key = k0 + c, ki = min(key, len - 1);
     const bf16_t* kr = base + E + (size_t)ki * 3 * E + 8 * g;
-    const bf16x8 kb0 = a3_ld16(kr), kb1 = a3_ld16(kr + 16), vb0 = a3_ld16(kr + E), vb1 = a3_ld16(kr + E + 16);
-    const float scale = rsqrtf(32.0f);
-    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    f32x16 dK, dV;
+    bf16x8 kb_[KS], vb_[KS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dK[r] = 0.0f; dV[r] = 0.0f; }
+    for (int t = 0; t < KS; ++t) { kb_[t] = a3_ld16(kr + 16 * t); vb_[t] = a3_ld16(kr + E + 16 * t); }
+    const float scale = rsqrtf((float)HD);
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    f32x16 dK[DB], dV[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) { dK[d] = a3_zero(); dV[d] = a3_zero(); }
     const int nb = LR >> 5;
     auto qrow = [&](int qb) { return base + (size_t)min(qb * 32 + c, len - 1) * 3 * E + 8 * g; };
     auto grow = [&](int qb) { return gbase + (size_t)min(qb * 32 + c, len - 1) * E + 8 * g; };
-    bf16x8 nq0 = a3_ld16(qrow(0)), nq1 = a3_ld16(qrow(0) + 16), ng0 = a3_ld16(grow(0)), ng1 = a3_ld16(grow(0) + 16);
-    for (int qb = 0; qb < nb; ++qb) {
-        const bf16x8 qa0 = nq0, qa1 = nq1, ga0 = ng0, ga1 = ng1;
-        if (qb + 1 < nb) {  // next block's Q / dctx rows in flight under this block's arithmetic
-            nq0 = a3_ld16(qrow(qb + 1)); nq1 = a3_ld16(qrow(qb + 1) + 16);
-            ng0 = a3_ld16(grow(qb + 1)); ng1 = a3_ld16(grow(qb + 1) + 16);
-        }
-        f32x16 S, dP;
+    bf16x8 nq[KS], ng[KS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { S[r] = 0.0f; dP[r] = 0.0f; }
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0, kb0, S, 0, 0, 0);
-        S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1, kb1, S, 0, 0, 0);
-        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga0, vb0, dP, 0, 0, 0);
-        dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga1, vb1, dP, 0, 0, 0);
+    for (int t = 0; t < KS; ++t) { nq[t] = a3_ld16(qrow(0) + 16 * t); ng[t] = a3_ld16(grow(0) + 16 * t); }
+    for (int qb = 0; qb < nb; ++qb) {
+        bf16x8 qa[KS], ga[KS];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) { qa[t] = nq[t]; ga[t] = ng[t]; }
+        if (qb + 1 < nb) {  // next block's Q / dctx rows in flight under this block's arithmetic
+#pragma unroll
+            for (int t = 0; t < KS; ++t) { nq[t] = a3_ld16(qrow(qb + 1) + 16 * t); ng[t] = a3_ld16(grow(qb + 1) + 16 * t); }
+        }
+        f32x16 S = a3_zero(), dP = a3_zero();
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[t], kb_[t], S, 0, 0, 0);
+            dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[t], vb_[t], dP, 0, 0, 0);
+        }
         float pm[16], ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -796,30 +832,63 @@ __global__ __launch_bounds__(256) void attn3_bwd_kv_kernel(const bf16_t* __restr
             pm[r] = pv * msk;
             ds[r] = pv * (dP[r] * msk - del_s[qq]) * scale;
         }
-        const bf16_t* gt = Gt + (size_t)c * LP + qb * 32 + 4 * g;
-        const bf16_t* qt = Qt + (size_t)c * LP + qb * 32 + 4 * g;
-        dV = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_pack(pm, 0), a3_ldt(gt), dV, 0, 0, 0);
-        dV = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_pack(pm, 1), a3_ldt(gt + 16), dV, 0, 0, 0);
-        dK = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_pack(ds, 0), a3_ldt(qt), dK, 0, 0, 0);
-        dK = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_pack(ds, 1), a3_ldt(qt + 16), dK, 0, 0, 0);
-    }
-    // accumulators: lane = head-dim column c, register r <-> key k0 + idx(r, g)
+        const bf16x8 p0 = a3_pack(pm, 0), p1 = a3_pack(pm, 1), s0 = a3_pack(ds, 0), s1 = a3_pack(ds, 1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int kk = k0 + a3_idx(r, g);
-        if (kk < len) {
-            bf16_t* o = dqkv + ((size_t)s * len + kk) * 3 * E + E + h * 32 + c;
-            o[0] = f2bf(dK[r]);
-            o[E] = f2bf(dV[r]);
+        for (int d = 0; d < DB; ++d) {
+            const bf16_t* gt = Gt + (size_t)(d * 32 + c) * LP + qb * 32 + 4 * g;
+            const bf16_t* qt = Qt + (size_t)(d * 32 + c) * LP + qb * 32 + 4 * g;
+            dV[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p0, a3_ldt(gt), dV[d], 0, 0, 0);
+            dV[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(p1, a3_ldt(gt + 16), dV[d], 0, 0, 0);
+            dK[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s0, a3_ldt(qt), dK[d], 0, 0, 0);
+            dK[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(s1, a3_ldt(qt + 16), dK[d], 0, 0, 0);
         }
     }
+    // accumulators: lane = head-dim column d * 32 + c, register r <-> key k0 + idx(r, g)
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kk = k0 + a3_idx(r, g);
+            if (kk < len) {
+                bf16_t* o = dqkv + ((size_t)s * len + kk) * 3 * E + E + h * HD + d * 32 + c;
+                o[0] = f2bf(dK[d][r]);
+                o[E] = f2bf(dV[d][r]);
+            }
+        }
+}
+
+template <int HD>
+int launch_attn3_fwd(const void* qkv, void* ctx, void* probs, int seqs, int len, int heads, float p_drop, uint64_t seed, hipStream_t st) {
+    const int LP = ((len + 31) & ~31) + 4;
+    const size_t lds = (size_t)HD * LP * 2;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_fwd_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn3_fwd_kernel<HD>), dim3(seqs * heads, cdiv(len, 128)), dim3(256), lds, st, (const bf16_t*)qkv, (bf16_t*)ctx,
+                       (float*)probs, len, heads, p_drop, seed);
+    SPV_LAUNCH_CHECK("spv_attention_fwd(v3)");
+    return 0;
+}
+template <int HD>
+int launch_attn3_bwd(const void* dctx, const void* qkv, const void* probs, void* dscores, void* dqkv, int seqs, int len, int heads,
+                     float p_drop, uint64_t seed, hipStream_t st) {
+    const int LR = (len + 31) & ~31, LP = LR + 4;
+    const size_t lds_q = (size_t)HD * LP * 2, lds_kv = (size_t)2 * HD * LP * 2 + (size_t)3 * LR * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_q_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_kv_kernel<HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    dim3 grid(seqs * heads, cdiv(len, 128));
+    hipLaunchKernelGGL((attn3_bwd_q_kernel<HD>), grid, dim3(256), lds_q, st, (const bf16_t*)dctx, (const bf16_t*)qkv, (const float*)probs,
+                       (float*)dscores, (bf16_t*)dqkv, len, heads, p_drop, seed);
+    SPV_LAUNCH_CHECK("spv_attention_bwd(v3 q)");
+    hipLaunchKernelGGL((attn3_bwd_kv_kernel<HD>), grid, dim3(256), lds_kv, st, (const bf16_t*)dctx, (const bf16_t*)qkv,
+                       (const float*)probs, (const float*)dscores, (bf16_t*)dqkv, len, heads, p_drop, seed);
+    SPV_LAUNCH_CHECK("spv_attention_bwd(v3 kv)");
+    return 0;
 }
 
 inline bool attn3_ok(int len, int heads, int hd, int dtype, const void* a, const void* b, const void* c) {
-    if (dtype != SPV_BF16 || hd != 32 || len < 2 || (heads * hd) % 8) return false;
+    if (dtype != SPV_BF16 || !(hd == 32 || hd == 64) || len < 2 || (heads * hd) % 8) return false;
     if (((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)c & 15)) return false;
     const size_t LP = ((len + 31) & ~31) + 4;
-    return 2 * 32 * LP * 2 + 3 * (LP - 4) * 4 <= 150 * 1024;
+    return 2 * (size_t)hd * LP * 2 + 3 * (LP - 4) * 4 <= 150 * 1024;
 }
 
 int check(const char* name, int seqs, int len, int heads, int hd, int dtype) {
@@ -836,13 +905,9 @@ extern "C" int spv_attention_fwd(const void* qkv, void* ctx, void* probs, int se
                                  float p_drop, uint64_t seed, void* stream) {
     if (check("spv_attention_fwd", seqs, len, heads, head_dim, dtype)) return 1;
     if (attn3_ok(len, heads, head_dim, dtype, qkv, ctx, probs)) {
-        const int LP = ((len + 31) & ~31) + 4;
-        const size_t lds = (size_t)32 * LP * 2;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((attn3_fwd_kernel<false>), dim3(seqs * heads, cdiv(len, 128)), dim3(256), lds, static_cast<hipStream_t>(stream),
-                           (const bf16_t*)qkv, (bf16_t*)ctx, (bf16_t*)nullptr, (float*)probs, len, heads, p_drop, seed);
-        SPV_LAUNCH_CHECK("spv_attention_fwd(v3)");
-        return 0;
+        hipStream_t st3 = static_cast<hipStream_t>(stream);
+        return head_dim == 32 ? launch_attn3_fwd<32>(qkv, ctx, probs, seqs, len, heads, p_drop, seed, st3)
+                              : launch_attn3_fwd<64>(qkv, ctx, probs, seqs, len, heads, p_drop, seed, st3);
     }
     if (dtype == SPV_BF16 && attn2_ok<bf16_t>(len, heads, head_dim, qkv, ctx))
         A2_DISPATCH(bf16_t, head_dim, launch_attn2_fwd, qkv, ctx, probs, seqs, len, heads, p_drop, seed, static_cast<hipStream_t>(stream));
@@ -859,20 +924,9 @@ extern "C" int spv_attention_bwd(const void* dctx, const void* qkv, const void* 
                                  int heads, int head_dim, int dtype, float p_drop, uint64_t seed, void* stream) {
     if (check("spv_attention_bwd", seqs, len, heads, head_dim, dtype)) return 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (attn3_ok(len, heads, head_dim, dtype, qkv, dctx, probs) && ((uintptr_t)dscores & 15) == 0) {
-        const int LR = (len + 31) & ~31, LP = LR + 4;
-        const size_t lds_q = (size_t)32 * LP * 2, lds_kv = (size_t)2 * 32 * LP * 2 + (size_t)3 * LR * 4;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn3_bwd_kv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        dim3 grid(seqs * heads, cdiv(len, 128));
-        hipLaunchKernelGGL(attn3_bwd_q_kernel, grid, dim3(256), lds_q, st, (const bf16_t*)dctx, (const bf16_t*)qkv, (const float*)probs,
-                           (float*)dscores, (bf16_t*)dqkv, len, heads, p_drop, seed);
-        SPV_LAUNCH_CHECK("spv_attention_bwd(v3 q)");
-        hipLaunchKernelGGL(attn3_bwd_kv_kernel, grid, dim3(256), lds_kv, st, (const bf16_t*)dctx, (const bf16_t*)qkv, (const float*)probs,
-                           (const float*)dscores, (bf16_t*)dqkv, len, heads, p_drop, seed);
-        SPV_LAUNCH_CHECK("spv_attention_bwd(v3 kv)");
-        return 0;
-    }
+    if (attn3_ok(len, heads, head_dim, dtype, qkv, dctx, probs) && ((uintptr_t)dscores & 15) == 0)
+        return head_dim == 32 ? launch_attn3_bwd<32>(dctx, qkv, probs, dscores, dqkv, seqs, len, heads, p_drop, seed, st)
+                              : launch_attn3_bwd<64>(dctx, qkv, probs, dscores, dqkv, seqs, len, heads, p_drop, seed, st);
     if (dtype == SPV_BF16 && attn2_ok<bf16_t>(len, heads, head_dim, qkv, dctx))
         A2_DISPATCH(bf16_t, head_dim, launch_attn2_bwd, dctx, qkv, probs, dscores, dqkv, seqs, len, heads, p_drop, seed, st);
     if (dtype == SPV_F32 && attn2_ok<float>(len, heads, head_dim, qkv, dctx))
