@@ -76,8 +76,11 @@ def test_harness_uint8_input_matches_float_input(tmp_path):
 
 
 @pytest.mark.gpu
-def test_first_steps_loss_curve_vs_oracle():
-    """the first optimisation steps on a fixed synthetic batch follow the oracle's loss curve (fp32)."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_first_steps_loss_curve_vs_oracle(fused):
+    """the first optimisation steps on a fixed synthetic batch follow the oracle's loss curve (fp32).
+    fused=True: torch's fused AdamW updates parameters WITHOUT bumping their version counters -- the transposed / bf16
+    weight copies the GEMMs read must follow anyway."""
     from conftest import load_model_fixture
     from spectre_vit.models.spectre.spectre import SpectreViT
     d, cfg = load_model_fixture("model_small_cut")
@@ -86,11 +89,11 @@ def test_first_steps_loss_curve_vs_oracle():
     m = SpectreViT(**cfg).to(dev)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     m.train()
-    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, fused=fused)
     img, labels = torch.from_numpy(d["img"]).to(dev), torch.from_numpy(d["labels"]).to(dev)
     sd64 = {k: np.asarray(v, np.float64) if v.dtype.kind == "f" else v for k, v in sd.items()}
     state = {}
-    for step in range(1, 5):
+    for step in range(1, 7):
         loss = torch.nn.functional.cross_entropy(m(img), labels)
         opt.zero_grad(set_to_none=True)
         loss.backward()
@@ -100,3 +103,49 @@ def test_first_steps_loss_curve_vs_oracle():
             mv = state.setdefault(k, [np.zeros_like(g), np.zeros_like(g)])
             sd64[k], mv[0], mv[1] = O.adamw_step(sd64[k], g, mv[0], mv[1], step)
         assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss), (step, loss.item(), ref_loss)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mixer", ["fft", "permut"])
+def test_bf16_training_uses_updated_weights(mixer):
+    """After optimizer steps (fused AdamW: no version bump) the bf16 forward must equal that of a fresh model loaded with
+    the updated state_dict, in train and in eval mode; a frozen bf16 shadow of the weights would keep the old output."""
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    cfg = dict(img_size=16, patch_size=4, in_channels=3, num_classes=16, embed_dim=64, num_encoders=2, num_heads=4, hidden_dim=96,
+               dropout=0.0, mixer=mixer)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = SpectreViT(**cfg).to(dev).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=5e-2, fused=True)  # large steps: stale weights would be obvious
+    x = torch.randn(8, 3, 16, 16, device=dev)
+    y = torch.randint(0, 16, (8,), device=dev)
+
+    def fwd(model):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return model(x).float()
+
+    out0 = fwd(m).detach().clone()
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(fwd(m), y).backward()
+        opt.step()
+    fresh = SpectreViT(**cfg).to(dev)
+    fresh.load_state_dict(m.state_dict())
+    for mode in ("train", "eval"):
+        getattr(m, mode)(); getattr(fresh, mode)()
+        with torch.no_grad():
+            a, b = fwd(m), fwd(fresh)
+        assert torch.equal(a, b), (mode, (a - b).abs().max().item())
+    assert (fwd(m).detach() - out0).abs().max().item() > 0.05  # and the steps did move the output
+    # inference-time cache: an optimizer step between two no_grad forwards invalidates it
+    m.eval()
+    with torch.no_grad():
+        before = fwd(m)
+    m.train()
+    opt.zero_grad(set_to_none=True)
+    torch.nn.functional.cross_entropy(fwd(m), y).backward()
+    opt.step()
+    m.eval(); fresh.load_state_dict(m.state_dict()); fresh.eval()
+    with torch.no_grad():
+        after, ref = fwd(m), fwd(fresh)
+    assert torch.equal(after, ref) and not torch.equal(after, before)

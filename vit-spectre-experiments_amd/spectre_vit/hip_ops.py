@@ -92,17 +92,24 @@ class _Cast(torch.autograd.Function):
 # weight shadows: compute-dtype copy of W and of W^T, rebuilt only when the parameter changes
 # ------------------------------------------------------------------------------------------------
 class _ShadowCache:
-    """(weight tensor, dtype) -> (W in dtype, W^T in dtype, padded to 8 columns).  Entries are validated by a weak
-    reference to the parameter (ids and addresses are recycled once a tensor dies) and by its version counter."""
+    """(weight tensor, dtype) -> (W in dtype, W^T in dtype, padded to 8 columns).
+
+    While a weight is being trained (grad mode on, requires_grad) the shadows are rebuilt at every forward: optimizers may
+    update parameters without touching the tensor's version counter -- ``torch.optim.AdamW(fused=True)`` does exactly that --
+    so no cheap test can prove a cached copy current, and a stale copy would silently freeze the layer.  Outside training
+    (eval / no_grad inference loops) entries are reused, validated by a weak reference to the parameter (ids and addresses
+    are recycled once a tensor dies), its version counter and the global optimizer-step epoch."""
 
     def __init__(self):
         self._d = {}
+        self.epoch = 0
 
     def get(self, w: torch.Tensor, dtype: torch.dtype):
         key = (id(w), dtype)
         ent = self._d.get(key)
-        ver = (w.data_ptr(), w._version, tuple(w.shape))
-        if ent is not None and ent[0]() is w and ent[1] == ver:
+        ver = (w.data_ptr(), w._version, tuple(w.shape), self.epoch)
+        training = torch.is_grad_enabled() and w.requires_grad
+        if not training and ent is not None and ent[0]() is w and ent[1] == ver:
             return ent[2], ent[3]
         n, k = w.shape
         wd = w.detach()
@@ -119,6 +126,17 @@ class _ShadowCache:
 
 
 _shadows = _ShadowCache()
+
+
+def invalidate_weight_shadows(*_args, **_kwargs):
+    """Drop every cached bf16 / transposed weight copy (needed only after updating weights in place, outside autograd's
+    view, between two no_grad forwards).  Registered as a global optimizer post-step hook."""
+    _shadows.epoch += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_step  # noqa: E402
+
+_register_post_step(invalidate_weight_shadows)  # any torch optimizer's step() invalidates the inference-time cache
 
 
 # ------------------------------------------------------------------------------------------------
