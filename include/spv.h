@@ -42,6 +42,10 @@ int spv_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n
  * of every image without its CLS row). */
 int spv_cast_transpose(const void* src, int src_dtype, void* dst, int dst_dtype, int rows, int cols, int ld,
                        int rows_per_group, int group_stride, int row_offset, void* stream);
+/* spv_weight_shadows: both operand layouts of an fp32 nn.Linear weight [rows, cols] (layers.py:85-86) in one pass: the plain
+ * copy in the compute dtype (plain may be NULL: fp32 reads the parameter itself) and the transposed copy [cols, ld >= rows]
+ * for the data-gradient GEMM.  Rebuilt every training step: optimizers update parameters in place. */
+int spv_weight_shadows(const float* w, void* plain, void* transposed, int rows, int cols, int ld, int dtype, void* stream);
 
 /* ---- dense contraction: C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ C) ------------------------
  * nn.Linear inside SpectreLinear (spectre_vit/models/spectre/layers.py:85-86,100), its data and

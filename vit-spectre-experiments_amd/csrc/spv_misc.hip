@@ -57,6 +57,31 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const TI* __restric
     }
 }
 
+// One pass over an fp32 weight [rows, cols]: the plain copy in the compute dtype (skipped when plain == nullptr) and the
+// transposed copy [cols, ld] (zero beyond rows) -- the two operand layouts the NT GEMMs read.  Run once per weight per
+// training step (the copies cannot be cached: see hip_ops._ShadowCache).
+template <typename TO>
+__global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restrict__ src, TO* __restrict__ plain, TO* __restrict__ tr,
+                                                            int rows, int cols, int ld) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.0f;
+        if (r < rows && c < cols) {
+            v = src[(size_t)r * cols + c];
+            if (plain != nullptr) io<TO>::st(plain + (size_t)r * cols + c, v);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < ld) io<TO>::st(tr + (size_t)c * ld + r, tile[tx][i]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -175,6 +200,21 @@ extern "C" int spv_cast_transpose(const void* src, int sd, void* dst, int dd, in
     else
         return spv_set_error("spv_cast_transpose: bad dtypes %d -> %d", sd, dd);
     SPV_LAUNCH_CHECK("spv_cast_transpose");
+    return 0;
+}
+
+extern "C" int spv_weight_shadows(const float* w, void* plain, void* transposed, int rows, int cols, int ld, int dtype, void* stream) {
+    SPV_CHECK(rows > 0 && cols > 0 && ld >= rows, "spv_weight_shadows: bad shape %d x %d, ld %d", rows, cols, ld);
+    SPV_CHECK(w != nullptr && transposed != nullptr, "spv_weight_shadows: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(cols, 64), cdiv(ld, 64));
+    if (dtype == SPV_BF16)
+        hipLaunchKernelGGL((weight_shadow_kernel<bf16_t>), grid, dim3(256), 0, st, w, (bf16_t*)plain, (bf16_t*)transposed, rows, cols, ld);
+    else if (dtype == SPV_F32)
+        hipLaunchKernelGGL((weight_shadow_kernel<float>), grid, dim3(256), 0, st, w, (float*)plain, (float*)transposed, rows, cols, ld);
+    else
+        return spv_set_error("spv_weight_shadows: bad dtype %d", dtype);
+    SPV_LAUNCH_CHECK("spv_weight_shadows");
     return 0;
 }
 

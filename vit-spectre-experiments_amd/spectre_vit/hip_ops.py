@@ -114,11 +114,9 @@ class _ShadowCache:
         n, k = w.shape
         wd = w.detach()
         wc = wd if dtype == torch.float32 else torch.empty((n, k), dtype=dtype, device=w.device)
-        if wc is not wd:
-            _native.call("spv_cast", _p(wd), F32, _p(wc), _DT[dtype], wd.numel(), _stream())
         ldt = (n + 7) // 8 * 8
         wt = torch.empty((k, ldt), dtype=dtype, device=w.device)
-        _native.call("spv_cast_transpose", _p(wd), F32, _p(wt), _DT[dtype], n, k, ldt, 0, 0, 0, _stream())
+        _native.call("spv_weight_shadows", _p(wd), 0 if wc is wd else _p(wc), _p(wt), n, k, ldt, _DT[dtype], _stream())
         if len(self._d) > 1024:
             self._d = {kk: e for kk, e in self._d.items() if e[0]() is not None}
         self._d[key] = (weakref.ref(w), ver, wc, wt)
