@@ -63,22 +63,47 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const TI* __restric
 template <typename TO>
 __global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restrict__ src, TO* __restrict__ plain, TO* __restrict__ tr,
                                                             int rows, int cols, int ld) {
-    __shared__ float tile[64][65];
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, c = c0 + tx;
-        float v = 0.0f;
-        if (r < rows && c < cols) {
-            v = src[(size_t)r * cols + c];
-            if (plain != nullptr) io<TO>::st(plain + (size_t)r * cols + c, v);
+    // 32 (rows) x 64 (cols) tile: 16-byte loads along the columns, the transposed copy leaves as 8 consecutive rows per thread
+    __shared__ float tile[32][65];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+    const bool vec = (cols & 3) == 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int rl = pass * 16 + (t >> 4), c4 = (t & 15) * 4;
+        const int r = r0 + rl, c = c0 + c4;
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (r < rows) {
+            if (vec && c + 3 < cols) {
+                const float4 f = *reinterpret_cast<const float4*>(src + (size_t)r * cols + c);
+                v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+                if (plain != nullptr) io<TO>::st4(plain + (size_t)r * cols + c, v);
+            } else {
+                for (int u = 0; u < 4; ++u)
+                    if (c + u < cols) {
+                        v[u] = src[(size_t)r * cols + c + u];
+                        if (plain != nullptr) io<TO>::st(plain + (size_t)r * cols + c + u, v[u]);
+                    }
+            }
         }
-        tile[i][tx] = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tile[rl][c4 + u] = v[u];
     }
     __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
-        const int c = c0 + i, r = r0 + tx;
-        if (c < cols && r < ld) io<TO>::st(tr + (size_t)c * ld + r, tile[tx][i]);
+    const int cl = t >> 2, r8 = (t & 3) * 8;  // column cl of the tile, rows r8 .. r8 + 7
+    const int c = c0 + cl;
+    if (c < cols) {
+        TO* o = tr + (size_t)c * ld + r0 + r8;
+        if (r0 + r8 + 7 < ld && (ld & 7) == 0) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = tile[r8 + u][cl]; b[u] = tile[r8 + 4 + u][cl]; }
+            io<TO>::st4(o, a);
+            io<TO>::st4(o + 4, b);
+        } else {
+            for (int u = 0; u < 8; ++u)
+                if (r0 + r8 + u < ld) io<TO>::st(o + u, tile[r8 + u][cl]);
+        }
     }
 }
 
@@ -207,7 +232,7 @@ extern "C" int spv_weight_shadows(const float* w, void* plain, void* transposed,
     SPV_CHECK(rows > 0 && cols > 0 && ld >= rows, "spv_weight_shadows: bad shape %d x %d, ld %d", rows, cols, ld);
     SPV_CHECK(w != nullptr && transposed != nullptr, "spv_weight_shadows: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    dim3 grid(cdiv(cols, 64), cdiv(ld, 64));
+    dim3 grid(cdiv(cols, 64), cdiv(ld, 32));
     if (dtype == SPV_BF16)
         hipLaunchKernelGGL((weight_shadow_kernel<bf16_t>), grid, dim3(256), 0, st, w, (bf16_t*)plain, (bf16_t*)transposed, rows, cols, ld);
     else if (dtype == SPV_F32)
