@@ -109,3 +109,31 @@ def test_oracle_normalize_u8_matches_totensor_normalize():
     x = torch.from_numpy(img).permute(0, 3, 1, 2).double() / 255.0
     ref = (x - torch.tensor(mean, dtype=torch.float64).view(1, 3, 1, 1)) / torch.tensor(std, dtype=torch.float64).view(1, 3, 1, 1)
     np.testing.assert_allclose(O.normalize_u8(img, mean, std), ref.numpy(), rtol=0, atol=1e-14)
+
+
+def test_c_abi_rejects_bad_arguments_before_any_launch(built):
+    """Error contract of the C-ABI: a bad call returns non-zero and leaves a message for spv_last_error(); the
+    ctypes wrapper raises RuntimeError with it.  Every call below fails argument validation on the host, so nothing is
+    launched (this test runs without a GPU)."""
+    from spectre_vit import _native
+    BF16, F32 = 1, 0
+    cases = [
+        ("spv_gemm_nt", (0, 0, 0, 0, 0, 128, 64, 0, 0, 128, BF16, BF16, 0, 1, 0, 0), "empty"),
+        ("spv_gemm_nt", (16, 16, 0, 16, 128, 128, 12, 12, 12, 128, BF16, BF16, 0, 1, 0, 0), "multiples of 8"),
+        ("spv_gemm_nt", (16, 16, 0, 16, 128, 128, 64, 64, 64, 128, 7, BF16, 0, 1, 0, 0), "in_dtype"),
+        ("spv_gemm_nt", (16, 16, 0, 16, 128, 128, 64, 64, 64, 128, BF16, BF16, 0, 4, 0, 0), "workspace"),
+        ("spv_gemm_tn", (16, 16, 16, 100, 128, 64, 100, 128, 128, F32, 0, 1, 0, 0), "multiples of 8"),
+        ("spv_spectre_tail_fwd", (16, 16, 16, 16, 16, 16, 16, 4, 64, 64, BF16, BF16, 1.5, 0, 0), "p_drop"),
+        ("spv_spectre_tail_fwd", (16, 16, 16, 16, 16, 16, 16, 4, 64, 64, 9, BF16, 0.0, 0, 0), "dtype"),
+        ("spv_add_layernorm_fwd", (16, 16, 16, 16, 16, 16, 16, 4, 64, 3, BF16, 0), "mode"),
+        ("spv_attention_fwd", (16, 16, 16, 2, 8, 2, 512, BF16, 0.0, 0, 0), "head_dim"),
+        ("spv_patchify", (16, 16, 0, 3, 32, 32, 4, 48, 0, BF16, 0), "bad shape"),
+        ("spv_patchify_u8", (16, 0, 0, 16, 2, 3, 32, 32, 4, 48, 0, BF16, 0), "mean"),
+        ("spv_weight_shadows", (16, 0, 16, 100, 64, 96, BF16, 0), "bad shape"),
+        ("spv_dropout", (16, 16, 10, 1.0, 0, BF16, 0), "p="),
+    ]
+    for name, args, needle in cases:
+        with pytest.raises(RuntimeError) as e:
+            _native.call(name, *args)
+        assert name.replace("_fwd", "") in str(e.value) or name in str(e.value), (name, str(e.value))
+        assert needle in str(e.value), (name, needle, str(e.value))
