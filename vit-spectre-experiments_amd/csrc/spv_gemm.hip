@@ -314,7 +314,7 @@ constexpr int GBK = 64;  // split-K slices of the direct-to-LDS kernel are multi
 // KB = bytes of K per tile row per stage: 128 (64 bf16, 2 x 32 KiB stages, 2 workgroups per CU: long-K problems) or
 // 64 (32 bf16, 2 x 16 KiB stages, 4 workgroups per CU: the skinny K = 512..768 layer GEMMs, which are bound by load
 // latency per K-step rather than by MFMA issue and want more independent tiles in flight per CU).
-template <typename TO, int KB>
+template <typename TO, int KB, int NST>
 __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                            const float* __restrict__ bias, TO* __restrict__ C,
                                                            float* __restrict__ ws, int M, int N, int K, int lda, int ldb,
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
     constexpr int IPW = (BM / RPI) / 4;       // DMA instructions per wave per operand per stage
     constexpr int STAGE = (BM + BN) * KB;     // bytes per stage
     constexpr int KE = KB / 2;                // bf16 elements of K per stage
-    constexpr int SM = 2 * STAGE > 36864 ? 2 * STAGE : 36864;  // the epilogue stage needs 36 KiB
+    constexpr int SM = NST * STAGE > 36864 ? NST * STAGE : 36864;  // the epilogue stage needs 36 KiB
     __shared__ __attribute__((aligned(1024))) unsigned char smem[SM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -377,12 +377,19 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
     const int frow = lane & 31, fh = lane >> 5, swz = swizzle(frow);  // 64-row / 32-row offsets do not change the swizzle
     const int fa_off = (wm * 64 + frow) * KB, fb_off = BM * KB + (wn * 64 + frow) * KB;
 
-    stage(0, kbeg);
+    // NST stages in an LDS ring, prefetch distance NST - 1.  With three stages the wait is counted: loads, LDS-DMA and
+    // stores retire in issue order, so leaving the youngest stage's 2 * IPW pieces outstanding means the stage about to
+    // be read has landed (in-kernel stamps on the 33280 x 768 x 512 layer GEMM: 250-280 cycles at this wait per K step
+    // instead of 760-850 with two stages and vmcnt(0)).
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (kbeg + s * KE < kend) stage(s, kbeg + s * KE);
     int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += KE, buf ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage `buf` has landed
-        __builtin_amdgcn_s_barrier();                     // everyone's has; everyone is done reading stage buf^1
-        if (k0 + KE < kend) stage(buf ^ 1, k0 + KE);
+    for (int k0 = kbeg; k0 < kend; k0 += KE) {
+        if (NST >= 3 && k0 + KE < kend) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage `buf` has landed
+        __builtin_amdgcn_s_barrier();                          // everyone's has; everyone is done reading the stage before
+        if (k0 + (NST - 1) * KE < kend) stage((buf + NST - 1) % NST, k0 + (NST - 1) * KE);
         const unsigned char* sa = smem + buf * STAGE + fa_off;
         const unsigned char* sb = smem + buf * STAGE + fb_off;
 #pragma unroll
@@ -400,6 +407,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
     store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
 }
@@ -541,15 +549,16 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
         // direct-to-LDS double-buffered kernel for long reductions (measured: 896 vs 795 TFLOP/s at 4096^3, 755 vs 700 on
         // the 512 x 8192 x 33280 weight gradient); the skinny K <= 1024 layer GEMMs are faster on the register-staged
         // kernel (42 vs 50 us at 33280 x 768 x 512: three workgroups per CU instead of two)
-        static const int force_kb = getenv("SPV_GEMM_KB") ? atoi(getenv("SPV_GEMM_KB")) : 0;  // tuning aid
-        if (K % GBK == 0 && k_per_split % GBK == 0 && (force_kb || kend_len(K, k_per_split) > 1024)) {
-            const int kb = force_kb ? force_kb : 128;
+        static const int force_kb = getenv("SPV_GEMM_KB") ? atoi(getenv("SPV_GEMM_KB")) : 0;  // tuning aid: 64 / 128 / -1 (off)
+        const bool big = (int64_t)tiles_m * tiles_n * splits >= 512;  // enough workgroups for 3 per CU to matter
+        if (force_kb >= 0 && K % GBK == 0 && k_per_split % GBK == 0 && (force_kb || kend_len(K, k_per_split) > 1024 || big)) {
+            const int kb = force_kb ? force_kb : (kend_len(K, k_per_split) > 1024 ? 128 : 64);
             if (kb == 64)
-                hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 64>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
+                hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 64, 3>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                    static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
                                    accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
             else
-                hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 128>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
+                hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 128, 2>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                    static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
                                    accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
             SPV_LAUNCH_CHECK("spv_gemm_nt(glds)");
