@@ -133,6 +133,17 @@ int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* dx, int bat
 int spv_fnet_mix(const void* x, void* y, const void* add_in, const float* twiddle, int batch, int tokens, int dim,
                  int dtype, float* workspace, void* stream);
 int64_t spv_fnet_workspace_floats(int batch, int tokens, int dim);
+/* First half of the encoder layer as ONE kernel each way: x1 = LayerNorm1(Re(fft2(x))) + x
+ * (spectre_vit/models/spectre/spectre.py:66 with the FFT mixer).  spv_fnet_ln_supported tells whether the fused kernels
+ * cover a shape (bf16, dim 512, 2 <= tokens <= 65); otherwise callers compose spv_fnet_mix with spv_add_layernorm_*.
+ *   fwd: prenorm = Re(fft2(x)) (kept for the backward), out = LN(prenorm) * gamma + beta + x, mean / rstd [batch*tokens].
+ *   bwd: dx = Re(fft2(LN1-backward(dout))) + dout; dgamma / dbeta [dim]; partials: batch * 2 * dim floats of scratch. */
+int spv_fnet_ln_supported(int tokens, int dim, int dtype);
+int spv_fnet_ln_fwd(const void* x, void* prenorm, void* out, const float* gamma, const float* beta, float* mean, float* rstd,
+                    const float* twiddle, int batch, int tokens, int dim, int dtype, void* stream);
+int spv_fnet_ln_bwd(const void* dout, const void* prenorm, const float* mean, const float* rstd, const float* gamma, void* dx,
+                    float* dgamma, float* dbeta, float* partials, const float* twiddle, int batch, int tokens, int dim, int dtype,
+                    void* stream);
 int64_t spv_fnet_twiddle_floats(int tokens);
 int spv_fnet_make_twiddle(float* twiddle, int tokens, void* stream);
 

@@ -301,6 +301,43 @@ def test_haar_dwt(ops, dtype, shape, axis, levels):
     check(X.grad, O.haar_dwt_bwd(dy, axis - 3, levels), tol, "dx")
 
 
+@pytest.mark.parametrize("B,N", [(3, 65), (2, 17), (5, 64), (2, 2)])
+def test_fnet_layernorm_residual_fused(ops, B, N):
+    """x1 = LayerNorm1(Re(fft2(x))) + x as one kernel each way (bf16, D = 512): forward, dx, dgamma, dbeta against the oracle
+    composition fnet_mix -> layernorm -> + x, and against the unfused kernels on the forward (the fused epilogue normalises
+    the bf16-rounded mixer output, exactly what the separate kernel reads back: equal up to the summation order)."""
+    D, dtype = 512, torch.bfloat16
+    rng = np.random.default_rng(B * 100 + N)
+    x = q(rng.standard_normal((B, N, D)) * 0.5, dtype)
+    g, be = rng.random(D) + 0.5, rng.standard_normal(D) * 0.1
+    dy = q(rng.standard_normal((B, N, D)), dtype)
+    X = t(x, dtype).requires_grad_(True)
+    G, Bt = t(g).requires_grad_(True), t(be).requires_grad_(True)
+    assert ops._native.call("spv_fnet_ln_supported", N, D, 1) == 1
+    Y = ops.FNetResidualFn.apply(X, G, Bt)
+    Y.backward(t(dy, dtype))
+    # oracle
+    m = O.fnet_mix_fwd(x)
+    mq = q(m, dtype)  # the pre-norm tensor is stored in bf16
+    ln, cache = O.layernorm_fwd(mq, g, be)
+    ref = ln + x
+    dm, dg_ref, db_ref = O.layernorm_bwd(dy, g, cache)
+    dx_ref = O.fnet_mix_bwd(q(dm, dtype)) + dy
+    scale = np.abs(m).max()
+    check(Y, ref, 3e-2, "x1")
+    assert np.abs(n64(X.grad) - dx_ref).max() <= 3e-2 * np.abs(dx_ref).max(), "dx"
+    check(G.grad, dg_ref, 3e-2, "dgamma")
+    check(Bt.grad, db_ref, 3e-2, "dbeta")
+    # unfused kernels on the same inputs: identical forward
+    m_u = ops._fnet_raw(t(x, dtype))
+    out_u, _ = ops._addln_forward(m_u.reshape(-1, D), t(x, dtype).reshape(-1, D), t(g), t(be), 0)
+    a, b = out_u.reshape(B, N, D).float(), Y.detach().float()
+    diff = (a - b).abs()
+    # same arithmetic on the same bf16-rounded values; only the order of the two row sums differs -> at most a bf16 ulp, rarely
+    assert float((diff > 0).float().mean()) < 1e-3 and float((diff / (b.abs() + 1e-3)).max()) <= 1.0 / 64, float(diff.max())
+    assert scale > 0
+
+
 # ------------------------------------------------------------------------------------------------ patch embeddings
 def test_spectral_patch_embed_golden(ops, golden_ops):
     from spectre_vit.models.spectre.spectre import SpectralPatchEmbed

@@ -305,10 +305,29 @@ __device__ __forceinline__ void v2_pass(unsigned char* re, unsigned char* im, in
     v2_wave_sync();
 }
 
+// LayerNorm-1 of the encoder layer fused into the mixer (reference spectre.py:66: norm1(mix(x)) + x):
+//   FUSE = 1 (forward): phase D normalises each finished row (a row = 64 consecutive chunks = one wave: statistics by wave
+//            reductions), adds the residual and writes x1; the pre-norm row is written too (the backward needs it).
+//   FUSE = 2 (backward): phase A turns the incoming gradient into the gradient of the pre-norm mixer output on the fly
+//            (LayerNorm backward per row) while filling LDS; the column sums (dgamma, dbeta) leave as one slab per
+//            workgroup.  Saves the add+LayerNorm kernels and one read + one write of a (B, N, D) tensor each way.
+struct FnetLn {
+    const float* gamma;
+    const float* beta;
+    float* mean;            // [batch * N]  (written by FUSE 1, read by FUSE 2)
+    float* rstd;
+    const bf16_t* res;      // FUSE 1: residual input (the mixer's own input x)
+    bf16_t* prenorm;        // FUSE 1: pre-norm mixer output, saved for the backward
+    const bf16_t* m_in;     // FUSE 2: that saved tensor
+    float* partials;        // FUSE 2: [batch][2][D] column sums of this workgroup
+};
+constexpr float V2_LN_EPS = 1e-5f;
+
+template <int FUSE>
 __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                            const uint4* __restrict__ wfrag, const float* __restrict__ wextra,
                                                            const float* __restrict__ wtw, int N, int stagger,
-                                                           const bf16_t* __restrict__ add_in) {
+                                                           const bf16_t* __restrict__ add_in, FnetLn ln) {
     extern __shared__ __attribute__((aligned(16))) float lds_f32[];
     unsigned char* lds = reinterpret_cast<unsigned char*>(lds_f32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -323,9 +342,60 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
         for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
     V2_STAMP(0);
     // ---- A: x -> LDS (bf16), pad row of an odd N zeroed
-    for (int c = tid; c < N * 64; c += 512) {
-        const int row = c >> 6, ch = c & 63;
-        *reinterpret_cast<uint4*>(lds + row * V2RS + v2_off(ch * 8)) = *reinterpret_cast<const uint4*>(x + base + (size_t)row * V2D + ch * 8);
+    if (FUSE == 2) {
+        // x is the gradient wrt x1 = LN(m) + x0: d m = rstd (dy g - mean(dy g) - xhat mean(dy g xhat)); one row per wave step
+        const int ch = tid & 63;
+        float gam[8], accg[8], accb[8];
+        {
+            const float4 g0 = *reinterpret_cast<const float4*>(ln.gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(ln.gamma + ch * 8 + 4);
+            gam[0] = g0.x; gam[1] = g0.y; gam[2] = g0.z; gam[3] = g0.w; gam[4] = g1.x; gam[5] = g1.y; gam[6] = g1.z; gam[7] = g1.w;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { accg[u] = 0.0f; accb[u] = 0.0f; }
+        for (int c = tid; c < N * 64; c += 512) {
+            const int row = c >> 6;
+            const uint4 dv = *reinterpret_cast<const uint4*>(x + base + (size_t)row * V2D + ch * 8);
+            const uint4 mv = *reinterpret_cast<const uint4*>(ln.m_in + base + (size_t)row * V2D + ch * 8);
+            const float mean = ln.mean[(size_t)blockIdx.x * N + row], rstd = ln.rstd[(size_t)blockIdx.x * N + row];
+            const unsigned dw[4] = {dv.x, dv.y, dv.z, dv.w}, mw[4] = {mv.x, mv.y, mv.z, mv.w};
+            float xh[8], t[8];
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d0 = __uint_as_float(dw[u] << 16), d1 = __uint_as_float(dw[u] & 0xffff0000u);
+                xh[2 * u] = (__uint_as_float(mw[u] << 16) - mean) * rstd;
+                xh[2 * u + 1] = (__uint_as_float(mw[u] & 0xffff0000u) - mean) * rstd;
+                accg[2 * u] += d0 * xh[2 * u]; accg[2 * u + 1] += d1 * xh[2 * u + 1];
+                accb[2 * u] += d0; accb[2 * u + 1] += d1;
+                t[2 * u] = d0 * gam[2 * u]; t[2 * u + 1] = d1 * gam[2 * u + 1];
+                s1 += t[2 * u] + t[2 * u + 1];
+                s2 += t[2 * u] * xh[2 * u] + t[2 * u + 1] * xh[2 * u + 1];
+            }
+            const float m1 = wave_sum(s1) * (1.0f / V2D), m2 = wave_sum(s2) * (1.0f / V2D);
+            unsigned o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                o[u] = (unsigned)f2bf(rstd * (t[2 * u] - m1 - xh[2 * u] * m2)) | ((unsigned)f2bf(rstd * (t[2 * u + 1] - m1 - xh[2 * u + 1] * m2)) << 16);
+            *reinterpret_cast<uint4*>(lds + row * V2RS + v2_off(ch * 8)) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        // column sums: the 8 waves hold the same 512 columns; meet in the 4 KiB behind the tile, in wave order
+        float* red = reinterpret_cast<float*>(lds + (size_t)std::max(2 * ((N + 1) / 2), 2 * (N / 2 + 1)) * V2RS);
+        for (int w = 0; w < 8; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    red[ch * 8 + u] = (w == 0 ? 0.0f : red[ch * 8 + u]) + accg[u];
+                    red[V2D + ch * 8 + u] = (w == 0 ? 0.0f : red[V2D + ch * 8 + u]) + accb[u];
+                }
+            }
+            __syncthreads();
+        }
+        for (int c = tid; c < 2 * V2D; c += 512) ln.partials[(size_t)blockIdx.x * 2 * V2D + c] = red[c];
+    } else {
+        for (int c = tid; c < N * 64; c += 512) {
+            const int row = c >> 6, ch = c & 63;
+            *reinterpret_cast<uint4*>(lds + row * V2RS + v2_off(ch * 8)) = *reinterpret_cast<const uint4*>(x + base + (size_t)row * V2D + ch * 8);
+        }
     }
     if (N & 1)
         for (int c = tid; c < 64; c += 512) *reinterpret_cast<uint4*>(lds + N * V2RS + v2_off(c * 8)) = make_uint4(0, 0, 0, 0);
@@ -445,9 +515,57 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
                              __uint_as_float(aw[u] & 0xffff0000u);
             o[u] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
         }
+        if (FUSE == 1) {
+            // the row (64 chunks) is this wave's: LayerNorm over the bf16-rounded mixer output (exactly what the unfused
+            // add+LayerNorm kernel would read back), then + residual
+            *reinterpret_cast<uint4*>(ln.prenorm + base + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+            float v[8];
+            float sm = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[2 * u] = __uint_as_float(o[u] << 16);
+                v[2 * u + 1] = __uint_as_float(o[u] & 0xffff0000u);
+                sm += v[2 * u] + v[2 * u + 1];
+            }
+            const float mean = wave_sum(sm) * (1.0f / V2D);
+            float sq = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float d = v[u] - mean; sq += d * d; }
+            const float rstd = rsqrtf(wave_sum(sq) * (1.0f / V2D) + V2_LN_EPS);
+            if (lane == 0) { ln.mean[(size_t)blockIdx.x * N + r] = mean; ln.rstd[(size_t)blockIdx.x * N + r] = rstd; }
+            const float4 g0 = *reinterpret_cast<const float4*>(ln.gamma + k0), g1 = *reinterpret_cast<const float4*>(ln.gamma + k0 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(ln.beta + k0), b1 = *reinterpret_cast<const float4*>(ln.beta + k0 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const uint4 rv = *reinterpret_cast<const uint4*>(ln.res + base + (size_t)r * V2D + k0);
+            const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float e0 = (v[2 * u] - mean) * rstd * gg[2 * u] + bb[2 * u] + __uint_as_float(rw[u] << 16);
+                const float e1 = (v[2 * u + 1] - mean) * rstd * gg[2 * u + 1] + bb[2 * u + 1] + __uint_as_float(rw[u] & 0xffff0000u);
+                o[u] = (unsigned)f2bf(e0) | ((unsigned)f2bf(e1) << 16);
+            }
+        }
         *reinterpret_cast<uint4*>(y + base + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
     V2_STAMP(9);
+}
+
+// dgamma / dbeta of the fused backward: out[c] = sum over workgroup slabs, 16 columns x 64 slab rows per workgroup
+__global__ __launch_bounds__(1024) void fnet_ln_fold_kernel(const float* __restrict__ partials, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int parts) {
+    __shared__ float red[64][17];
+    const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;  // < 2 * V2D
+    float s = 0.0f;
+    for (int w = py; w < parts; w += 64) s += partials[(size_t)w * 2 * V2D + c];
+    red[py][cx] = s;
+    __syncthreads();
+    if (py == 0) {
+        float t = 0.0f;
+        for (int q = 0; q < 64; ++q) t += red[q][cx];
+        if (c < V2D) dgamma[c] = t;
+        else dbeta[c - V2D] = t;
+    }
 }
 
 // ---------------- generic fallback (any tokens, dim): two direct-DFT kernels through an fp32 workspace
@@ -614,10 +732,10 @@ extern "C" int spv_fnet_mix(const void* x, void* y, const void* add_in, const fl
         const int v2_stagger = stagger_env >= 0 ? stagger_env : (batch >= 512 ? 1 : 0);  // x 8128 cycles (~3.5 us)
         const int rows = std::max(2 * ((tokens + 1) / 2), 2 * (tokens / 2 + 1));
         const size_t lds = (size_t)rows * V2RS;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(fnet_mfma_kernel, dim3(batch), dim3(512), lds, st, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(fnet_mfma_kernel<0>, dim3(batch), dim3(512), lds, st, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y),
                            reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)), twiddle + v2_extra_off(tokens),
-                           twiddle + v2_tw_off(tokens), tokens, v2_stagger, static_cast<const bf16_t*>(add_in));
+                           twiddle + v2_tw_off(tokens), tokens, v2_stagger, static_cast<const bf16_t*>(add_in), FnetLn{});
         SPV_LAUNCH_CHECK("spv_fnet_mix(v2)");
         return 0;
     }
@@ -686,5 +804,48 @@ extern "C" int spv_haar_dwt(const void* x, void* y, int batch, int tokens, int d
         SPV_LAUNCH_CHECK("spv_haar_dwt");
         src = dst;
     }
+    return 0;
+}
+
+
+// ---- mixer + LayerNorm-1 + residual as one kernel each way (bf16, dim 512, tokens <= 65: the shapes of fnet_mfma_kernel)
+extern "C" int spv_fnet_ln_supported(int tokens, int dim, int dtype) {
+    static const bool off = getenv("SPV_FNET_NO_V2") != nullptr || getenv("SPV_FNET_NO_FUSE") != nullptr;
+    return (!off && dtype == SPV_BF16 && dim == V2D && tokens >= 2 && tokens <= 65) ? 1 : 0;
+}
+
+static size_t fnet_v2_lds(int tokens) { return (size_t)std::max(2 * ((tokens + 1) / 2), 2 * (tokens / 2 + 1)) * V2RS; }
+
+extern "C" int spv_fnet_ln_fwd(const void* x, void* prenorm, void* out, const float* gamma, const float* beta, float* mean, float* rstd,
+                               const float* twiddle, int batch, int tokens, int dim, int dtype, void* stream) {
+    SPV_CHECK(batch > 0 && spv_fnet_ln_supported(tokens, dim, dtype), "spv_fnet_ln_fwd: unsupported shape %d x %d x %d / dtype %d", batch,
+              tokens, dim, dtype);
+    SPV_CHECK(twiddle && gamma && beta && mean && rstd && prenorm, "spv_fnet_ln_fwd: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    FnetLn ln{gamma, beta, mean, rstd, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(prenorm), nullptr, nullptr};
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(fnet_mfma_kernel<1>, dim3(batch), dim3(512), fnet_v2_lds(tokens), st, static_cast<const bf16_t*>(x),
+                       static_cast<bf16_t*>(out), reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)), twiddle + v2_extra_off(tokens),
+                       twiddle + v2_tw_off(tokens), tokens, 0, static_cast<const bf16_t*>(nullptr), ln);
+    SPV_LAUNCH_CHECK("spv_fnet_ln_fwd");
+    return 0;
+}
+
+extern "C" int spv_fnet_ln_bwd(const void* dout, const void* prenorm, const float* mean, const float* rstd, const float* gamma, void* dx,
+                               float* dgamma, float* dbeta, float* partials, const float* twiddle, int batch, int tokens, int dim,
+                               int dtype, void* stream) {
+    SPV_CHECK(batch > 0 && spv_fnet_ln_supported(tokens, dim, dtype), "spv_fnet_ln_bwd: unsupported shape %d x %d x %d / dtype %d", batch,
+              tokens, dim, dtype);
+    SPV_CHECK(twiddle && gamma && mean && rstd && prenorm && dgamma && dbeta && partials, "spv_fnet_ln_bwd: null pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    FnetLn ln{gamma, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), nullptr, nullptr, static_cast<const bf16_t*>(prenorm), partials};
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // input = dout (LayerNorm backward applied while it is staged); + dout again at the end: the residual path
+    hipLaunchKernelGGL(fnet_mfma_kernel<2>, dim3(batch), dim3(512), fnet_v2_lds(tokens) + 2 * V2D * sizeof(float), st,
+                       static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dx), reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)),
+                       twiddle + v2_extra_off(tokens), twiddle + v2_tw_off(tokens), tokens, 0, static_cast<const bf16_t*>(dout), ln);
+    SPV_LAUNCH_CHECK("spv_fnet_ln_bwd");
+    hipLaunchKernelGGL(fnet_ln_fold_kernel, dim3(2 * V2D / 16), dim3(1024), 0, st, partials, dgamma, dbeta, batch);
+    SPV_LAUNCH_CHECK("spv_fnet_ln_bwd(fold)");
     return 0;
 }

@@ -41,6 +41,9 @@ SIGNATURES = {
     "spv_fnet_workspace_floats": [c_i, c_i, c_i],
     "spv_fnet_twiddle_floats": [c_i],
     "spv_fnet_make_twiddle": [c_vp, c_i, c_vp],
+    "spv_fnet_ln_supported": [c_i, c_i, c_i],
+    "spv_fnet_ln_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "spv_fnet_ln_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_rfft_real": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_haar_dwt": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "spv_patchify": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
@@ -59,7 +62,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"spv_last_error": ctypes.c_char_p, "spv_rowop_partial_floats": c_i64, "spv_fnet_workspace_floats": c_i64,
              "spv_fnet_twiddle_floats": c_i64}
-_NO_STATUS = set(_RESTYPES) | {"spv_version"}
+_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported"}
 
 _lib = None
 

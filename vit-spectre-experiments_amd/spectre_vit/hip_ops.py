@@ -181,8 +181,13 @@ class KernelTimer:
         if name == "gemm":
             M, N, K, dt = key
             return "mfma", 2.0 * M * N * K, PEAK_TFLOPS[dt] * 1e12
-        B, N, D, dt = key  # fnet: read x once + write y once
-        return "hbm", 2.0 * B * N * D * (2 if dt == BF16 else 4), PEAK_HBM_GBS * 1e9
+        B, N, D, dt = key
+        es = 2 if dt == BF16 else 4
+        if name == "fnet_ln_fwd":  # mixer + LayerNorm-1 + residual: read x, write the pre-norm tensor and x1
+            return "hbm", 3.0 * B * N * D * es, PEAK_HBM_GBS * 1e9
+        if name == "fnet_ln_bwd":  # read dout and the pre-norm tensor, write dx
+            return "hbm", 3.0 * B * N * D * es, PEAK_HBM_GBS * 1e9
+        return "hbm", 2.0 * B * N * D * es, PEAK_HBM_GBS * 1e9  # fnet_mix: read x once + write y once
 
     def summary(self):
         out = []
@@ -907,10 +912,29 @@ class FNetResidualFn(torch.autograd.Function):
         _require_gpu(x)
         B, N, D = x.shape
         xc = x.contiguous()
+        ctx.shape = (B, N, D)
+        if _native.call("spv_fnet_ln_supported", N, D, _dt(xc)):
+            # one kernel: mixer, LayerNorm statistics per finished row, residual
+            dev = xc.device
+            m = torch.empty_like(xc)
+            out = torch.empty_like(xc)
+            mean = torch.empty((B * N,), dtype=torch.float32, device=dev)
+            rstd = torch.empty_like(mean)
+            tw = _fnet_twiddle(N, dev)
+
+            def launch():
+                _native.call("spv_fnet_ln_fwd", _p(xc), _p(m), _p(out), _p(n1w), _p(n1b), _p(mean), _p(rstd), _p(tw), B, N, D, _dt(xc),
+                             _stream())
+
+            if _timer is not None:
+                _timer.bracket("fnet_ln_fwd", (B, N, D, _dt(xc)), launch)
+            else:
+                launch()
+            ctx.saved = ("fused", m, mean, rstd, n1w, (_sink(n1w), _sink(n1b)))
+            return out
         m = _fnet_raw(xc)
         out, sn = _addln_forward(m.reshape(-1, D), xc.reshape(-1, D), n1w, n1b, 0)
         ctx.saved = sn
-        ctx.shape = (B, N, D)
         return out.reshape(B, N, D)
 
     @staticmethod
@@ -920,6 +944,24 @@ class FNetResidualFn(torch.autograd.Function):
         d2 = dout.reshape(-1, D)
         if not d2.is_contiguous():
             d2 = d2.contiguous()
+        if isinstance(sn[0], str):  # ("fused", ...)
+            _, m, mean, rstd, gamma, sinks = sn
+            dev = m.device
+            dx = torch.empty_like(m)
+            dn1w = _grad_buf(sinks[0], (D,), dev)
+            dn1b = _grad_buf(sinks[1], (D,), dev)
+            partials = torch.empty((B * 2 * D,), dtype=torch.float32, device=dev)
+            tw = _fnet_twiddle(N, dev)
+
+            def launch():
+                _native.call("spv_fnet_ln_bwd", _p(d2), _p(m), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dn1w), _p(dn1b), _p(partials),
+                             _p(tw), B, N, D, _dt(m), _stream())
+
+            if _timer is not None:
+                _timer.bracket("fnet_ln_bwd", (B, N, D, _dt(m)), launch)  # includes the tiny dgamma / dbeta fold
+            else:
+                launch()
+            return dx, dn1w, dn1b
         dm, dn1w, dn1b = _addln_backward(d2, sn)
         dx = _fnet_raw(dm.reshape(B, N, D), add_in=d2)  # symmetric operator; + the residual gradient, folded in
         return dx, dn1w, dn1b
