@@ -95,6 +95,25 @@ int spv_spectre_tail_bwd(const void* dout, const void* h, const float* mean, con
                          float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype,
                          int dout_dtype, float p_drop, uint64_t seed, const void* dx_add, void* stream);
 int64_t spv_rowop_partial_floats(int n);
+/* Second half of the encoder layer's elementwise work as ONE kernel each way:
+ *   f3 = SpectreLinear3-tail(h3, f1) (as spv_spectre_tail_fwd), x2 = LayerNorm2(x1 + f3)   (spectre.py:67, 70-73)
+ * spv_tail_ln_supported: shapes covered (512 outputs from 768 inputs, either dtype); otherwise compose
+ * spv_spectre_tail_* with spv_add_layernorm_* (mode 1).
+ *   fwd: out = f3 (kept: the backward re-forms x1 + f3 from it), out2 = x2, mean/rstd of the tail's LayerNorm,
+ *        mean2/rstd2 of LayerNorm-2; res = x1.
+ *   bwd: ds = LayerNorm2-backward(dout2) (written: the residual branch needs it) is used at once as the tail's incoming
+ *        gradient; dh, dx_pool, dgamma, dbeta, dbias as spv_spectre_tail_bwd; dgamma2, dbeta2 of LayerNorm-2;
+ *        partials: spv_tail_ln_partial_floats(n) floats. */
+int spv_tail_ln_supported(int n, int k_in, int dtype);
+int64_t spv_tail_ln_partial_floats(int n);
+int spv_spectre_tail_ln_fwd(const void* h, const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
+                            const void* res, const float* gamma2, const float* beta2, void* out2, float* mean2, float* rstd2, int rows,
+                            int n, int k_in, int dtype, float p_drop, uint64_t seed, void* stream);
+int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const void* res, const float* mean2, const float* rstd2,
+                            const float* gamma2, void* ds, float* dgamma2, float* dbeta2, const void* h, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, void* dh, void* dx_pool, float* dgamma,
+                            float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype, float p_drop,
+                            uint64_t seed, void* stream);
 
 /* ---- residual + LayerNorm ------------------------------------------------------------------------
  * mode 0: out = LN(a) + b      norm1(mix(x)) + x   spectre_vit/models/spectre/spectre.py:66

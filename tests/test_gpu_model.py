@@ -94,6 +94,35 @@ def test_model_vs_oracle_mixers(mixer, kw, dtype):
         check(p.grad, gref[k], tol * 3, "grad " + k)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layer_at_small_widths_vs_oracle(dtype):
+    """One encoder layer at the real Small widths (E 512, F 768, N 65, FFT mixer): the shapes on which the fused kernels run
+    (mixer + LayerNorm-1 + residual in bf16; linear3 tail + residual + LayerNorm-2 in both dtypes), against the float64 oracle."""
+    cfg = dict(small_cfg(), num_encoders=1)
+    torch.manual_seed(7)
+    m = build(cfg, mixer="fft")
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.ndim == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(4, 3, 32, 32, generator=g)
+    labels = torch.randint(0, 100, (4,), generator=g)
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    params = O.params_from_state_dict(sd, 1, "fft", np.float64)
+    logits_ref, cls_ref, cache = O.spectre_vit_fwd(img.numpy().astype(np.float64), params, 4, "fft")
+    _, dlog = O.cross_entropy_fwd_bwd(logits_ref, labels.numpy())
+    gref = O.grads_to_state_dict(O.spectre_vit_bwd(dlog, params, 4, cache, "fft"))
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        logits, cls = m(img.to(dev()), return_features=True)
+    torch.nn.CrossEntropyLoss()(logits, labels.to(dev())).backward()
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    check(logits, logits_ref, tol, "logits")
+    check(cls, cls_ref, tol, "cls")
+    for k, p in m.named_parameters():
+        check(p.grad, gref[k], tol * 3, "grad " + k)
+
+
 def small_cfg():
     # configs/spectre_vit_cifar100.py:3-20 of the reference
     return dict(img_size=32, patch_size=4, in_channels=3, num_classes=100, embed_dim=512, num_encoders=4, num_heads=16,

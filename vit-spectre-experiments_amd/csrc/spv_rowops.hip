@@ -526,7 +526,8 @@ __global__ __launch_bounds__(RT) void addln_bwd_kernel(const void* __restrict__ 
 constexpr int FOLD_COLS = 16, FOLD_ROWS = 64;
 __global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void fold_partials_kernel(const float* __restrict__ partials, float* __restrict__ o0,
                                                                              float* __restrict__ o1, float* __restrict__ o2,
-                                                                             int parts, int np, int n) {
+                                                                             int parts, int np, int n, float* __restrict__ o3 = nullptr,
+                                                                             float* __restrict__ o4 = nullptr) {
     __shared__ float red[FOLD_ROWS][FOLD_COLS + 1];
     const int cx = threadIdx.x % FOLD_COLS, py = threadIdx.x / FOLD_COLS;
     const int c = blockIdx.x * FOLD_COLS + cx;
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void fold_partials_kernel(co
     if (py == 0 && c < total) {
         const float t = (red[0][cx] + red[FOLD_ROWS / 4][cx]) + (red[FOLD_ROWS / 2][cx] + red[3 * FOLD_ROWS / 4][cx]);
         const int p = c / n, cc = c % n;
-        float* o = p == 0 ? o0 : (p == 1 ? o1 : o2);
+        float* o = p == 0 ? o0 : (p == 1 ? o1 : (p == 2 ? o2 : (p == 3 ? o3 : o4)));
         if (o) o[cc] = t;
     }
 }
@@ -590,12 +591,30 @@ template <int CNT> __device__ __forceinline__ void st_span(void* base, size_t of
     }
 }
 
-template <int CO, int CI, bool FASTG>
+// LayerNorm-2 of the encoder layer riding on the linear3 tail (reference spectre.py:67: norm2(x1 + ff(x1))): the tail's
+// output row f3 is complete in one wave, so x2 = LN2(x1 + f3) follows in registers (forward), and in the backward the
+// LayerNorm-2 gradient ds is formed in registers and used at once as the tail's incoming gradient.  Saves the
+// add+LayerNorm kernels and one read of f3 (forward) / ds (backward).  f3 is still written: the backward recomputes x1 + f3
+// from the same bf16 tensors the unfused kernels read, so both paths give the same numbers.
+struct TailLn2 {
+    const void* res;        // x1: the residual added before LayerNorm-2
+    const float* gamma2;
+    const float* beta2;
+    void* out2;             // forward: x2
+    float* mean2;           // forward writes, backward reads
+    float* rstd2;
+    const void* dout2;      // backward: gradient wrt x2
+    const void* f3;         // backward: the tail's forward output
+    void* ds;               // backward: gradient wrt (x1 + f3), also needed by the residual branch
+};
+__device__ __forceinline__ float round_store(float v, int bf) { return bf ? bf2f(f2bf(v)) : v; }
+
+template <int CO, int CI, bool FASTG, bool LN2>
 __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restrict__ h, const void* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              void* __restrict__ out, float* __restrict__ mean_o,
                                                              float* __restrict__ rstd_o, int rows, int bf, int out_bf, float p_drop,
-                                                             uint64_t seed) {
+                                                             uint64_t seed, TailLn2 ln) {
     constexpr int n = 64 * CO, k_in = 64 * CI;
     const int lane = threadIdx.x & 63;
     const int wave_g = blockIdx.x * RW + (threadIdx.x >> 6);
@@ -643,34 +662,88 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
         }
         st_span<CO>(out, (size_t)row * n + lane * CO, out_bf, o);
         if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+        if (LN2) {
+            float rv[CO], g2[CO], b2[CO];
+            ld_span<CO>(ln.res, (size_t)row * n + lane * CO, bf, rv);
+            float sm = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) { rv[c] += round_store(o[c], out_bf); sm += rv[c]; }  // x1 + f3 as the stored f3 reads back
+            const float mean2 = wave_sum(sm) / (float)n;
+            float q2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) { const float d = rv[c] - mean2; q2 += d * d; }
+            const float rstd2 = rsqrtf(wave_sum(q2) / (float)n + LN_EPS);
+            ld_span<CO>(ln.gamma2, (size_t)lane * CO, 0, g2);
+            ld_span<CO>(ln.beta2, (size_t)lane * CO, 0, b2);
+#pragma unroll
+            for (int c = 0; c < CO; ++c) rv[c] = (rv[c] - mean2) * rstd2 * g2[c] + b2[c];
+            st_span<CO>(ln.out2, (size_t)row * n + lane * CO, bf, rv);
+            if (lane == 0) { ln.mean2[row] = mean2; ln.rstd2[row] = rstd2; }
+        }
     }
 }
 
 // Column sums (dgamma, dbeta, dbias) live in LDS, not registers: 3*CO accumulators per lane pushed the register count
 // past the 4-waves/SIMD budget (spills).  Each wave owns [3][CO/4][64] float4 slots, lane-linear (conflict-free b128).
-template <int CO, int CI, bool FASTG>
+template <int CO, int CI, bool FASTG, bool LN2>
 __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restrict__ dout, const void* __restrict__ h,
                                                              const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              void* __restrict__ dh, void* __restrict__ dxp, float* __restrict__ partials,
                                                              int rows, int bf, int dout_bf, float p_drop, uint64_t seed,
-                                                             const void* __restrict__ dx_add) {
+                                                             const void* __restrict__ dx_add, TailLn2 ln) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int n = 64 * CO, k_in = 64 * CI, Q = CO / 4;
+    constexpr int NP = LN2 ? 5 : 3;  // column-sum arrays: dgamma, dbeta, dbias (+ LayerNorm-2's dgamma, dbeta)
     static_assert(CO % 4 == 0, "lane span must be whole float4s");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_g = blockIdx.x * RW + wave;
     const int nwaves = gridDim.x * RW;
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    float4* accw = reinterpret_cast<float4*>(lds) + (size_t)wave * 3 * Q * 64 + lane;  // slot (p, q) at accw[(p*Q+q)*64]
+    float4* accw = reinterpret_cast<float4*>(lds) + (size_t)wave * NP * Q * 64 + lane;  // slot (p, q) at accw[(p*Q+q)*64]
 #pragma unroll
-    for (int i = 0; i < 3 * Q; ++i) accw[i * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int i = 0; i < NP * Q; ++i) accw[i * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int row = wave_g; row < rows; row += nwaves) {
         const float mean = mean_i[row], rstd = rstd_i[row];
         const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
         float hv[CO], dv[CO], dxh[CO];
+        if (LN2) {
+            // incoming gradient = LayerNorm-2 backward of dout2 at s = x1 + f3, formed here instead of by a separate kernel
+            float sv[CO], tv[CO];
+            ld_span<CO>(ln.f3, (size_t)row * n + lane * CO, bf, sv);
+            ld_span<CO>(ln.res, (size_t)row * n + lane * CO, bf, tv);
+            ld_span<CO>(ln.dout2, (size_t)row * n + lane * CO, bf, dv);
+            const float mean2 = ln.mean2[row], rstd2 = ln.rstd2[row];
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                float g2[4];
+                ld_span<4>(ln.gamma2, (size_t)lane * CO + 4 * q, 0, g2);
+                float4 v3 = accw[(3 * Q + q) * 64], v4 = accw[(4 * Q + q) * 64];
+                float a3[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * q + e;
+                    const float xh = (sv[c] + tv[c] - mean2) * rstd2;
+                    a3[e] = dv[c] * xh;
+                    sv[c] = xh;               // xhat2
+                    tv[c] = dv[c] * g2[e];    // dy g
+                    t1 += tv[c];
+                    t2 += tv[c] * xh;
+                }
+                v3.x += a3[0]; v3.y += a3[1]; v3.z += a3[2]; v3.w += a3[3];
+                v4.x += dv[4 * q]; v4.y += dv[4 * q + 1]; v4.z += dv[4 * q + 2]; v4.w += dv[4 * q + 3];
+                accw[(3 * Q + q) * 64] = v3;
+                accw[(4 * Q + q) * 64] = v4;
+            }
+            const float n1 = wave_sum(t1) / (float)n, n2 = wave_sum(t2) / (float)n;
+#pragma unroll
+            for (int c = 0; c < CO; ++c) dv[c] = round_store(rstd2 * (tv[c] - n1 - sv[c] * n2), bf);
+            st_span<CO>(ln.ds, (size_t)row * n + lane * CO, bf, dv);
+        } else {
+            ld_span<CO>(dout, (size_t)row * n + lane * CO, dout_bf, dv);
+        }
         ld_span<CO>(h, (size_t)row * n + lane * CO, bf, hv);
-        ld_span<CO>(dout, (size_t)row * n + lane * CO, dout_bf, dv);
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -734,14 +807,14 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
     }
     __syncthreads();
     // sum the 4 waves' slots in wave order, one slab per workgroup: slab[p*n + col], col = lane*CO + 4q + e
-    float* slab = partials + (size_t)blockIdx.x * 3 * n;
-    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) {
+    float* slab = partials + (size_t)blockIdx.x * NP * n;
+    for (int i = threadIdx.x; i < NP * n; i += blockDim.x) {
         const int p = i / n, col = i - p * n;
         const int l = col / CO, r = col - l * CO;
         const int off = (((p * Q + (r >> 2)) * 64 + l) << 2) + (r & 3);
         float v = lds[off];
 #pragma unroll
-        for (int w = 1; w < RW; ++w) v += lds[w * 3 * n + off];
+        for (int w = 1; w < RW; ++w) v += lds[w * NP * n + off];
         slab[i] = v;
     }
 }
@@ -812,8 +885,8 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
         dim3 lgrid(std::min(cdiv(rows, RW), 2048));
 #define LC_FWD(CO, CI)                                                                                                        \
         if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
-            if (fast) hipLaunchKernelGGL((tail_fwd_lc_kernel<CO, CI, true>), lgrid, dim3(RT), 0, static_cast<hipStream_t>(stream), h, x, gamma, beta, out, mean, rstd, rows, bfl, obf, p_drop, seed); \
-            else hipLaunchKernelGGL((tail_fwd_lc_kernel<CO, CI, false>), lgrid, dim3(RT), 0, static_cast<hipStream_t>(stream), h, x, gamma, beta, out, mean, rstd, rows, bfl, obf, p_drop, seed);    \
+            if (fast) hipLaunchKernelGGL((tail_fwd_lc_kernel<CO, CI, true, false>), lgrid, dim3(RT), 0, static_cast<hipStream_t>(stream), h, x, gamma, beta, out, mean, rstd, rows, bfl, obf, p_drop, seed, TailLn2{}); \
+            else hipLaunchKernelGGL((tail_fwd_lc_kernel<CO, CI, false, false>), lgrid, dim3(RT), 0, static_cast<hipStream_t>(stream), h, x, gamma, beta, out, mean, rstd, rows, bfl, obf, p_drop, seed, TailLn2{});    \
             SPV_LAUNCH_CHECK("spv_spectre_tail_fwd(lc)");                                                                     \
             return 0;                                                                                                         \
         }
@@ -848,8 +921,8 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
 #define LC_BWD(CO, CI)                                                                                                        \
         if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
             hipStream_t lst = static_cast<hipStream_t>(stream);                                                               \
-            if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add); \
-            else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add);    \
+            if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{}); \
+            else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{});    \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc)");                                                                     \
             hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, lst, partials, dgamma, dbeta, dbias, lwgs, 3, n); \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc fold)");                                                                \
@@ -868,6 +941,51 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd");
     hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, wgs, 3, n);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(fold)");
+    return 0;
+}
+
+// ---- linear3 tail + residual + LayerNorm-2 as one kernel each way (512 outputs from 768 inputs: the lane-contiguous <8, 12> kernels)
+extern "C" int spv_tail_ln_supported(int n, int k_in, int dtype) {
+    static const bool off = getenv("SPV_TAIL_NO_FUSE") != nullptr;
+    return (!off && n == 512 && k_in == 768 && check_dtype(dtype)) ? 1 : 0;
+}
+extern "C" int64_t spv_tail_ln_partial_floats(int n) { return (int64_t)BWD_MAX_WG * 5 * n; }
+
+extern "C" int spv_spectre_tail_ln_fwd(const void* h, const void* x, const float* gamma, const float* beta, void* out, float* mean,
+                                       float* rstd, const void* res, const float* gamma2, const float* beta2, void* out2, float* mean2,
+                                       float* rstd2, int rows, int n, int k_in, int dtype, float p_drop, uint64_t seed, void* stream) {
+    SPV_CHECK(rows > 0 && spv_tail_ln_supported(n, k_in, dtype), "spv_spectre_tail_ln_fwd: unsupported shape %d -> %d / dtype %d", k_in, n, dtype);
+    SPV_CHECK(p_drop >= 0.0f && p_drop < 1.0f, "spv_spectre_tail_ln_fwd: p_drop=%f", p_drop);
+    SPV_CHECK(h && x && gamma && beta && out && mean && rstd && res && gamma2 && beta2 && out2 && mean2 && rstd2, "spv_spectre_tail_ln_fwd: null pointer");
+    const int bfl = dtype == SPV_BF16;
+    TailLn2 ln{res, gamma2, beta2, out2, mean2, rstd2, nullptr, nullptr, nullptr};
+    dim3 lgrid(std::min(cdiv(rows, RW), 2048));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bfl) hipLaunchKernelGGL((tail_fwd_lc_kernel<8, 12, true, true>), lgrid, dim3(RT), 0, st, h, x, gamma, beta, out, mean, rstd, rows, bfl, bfl, p_drop, seed, ln);
+    else hipLaunchKernelGGL((tail_fwd_lc_kernel<8, 12, false, true>), lgrid, dim3(RT), 0, st, h, x, gamma, beta, out, mean, rstd, rows, bfl, bfl, p_drop, seed, ln);
+    SPV_LAUNCH_CHECK("spv_spectre_tail_ln_fwd");
+    return 0;
+}
+
+extern "C" int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const void* res, const float* mean2, const float* rstd2,
+                                       const float* gamma2, void* ds, float* dgamma2, float* dbeta2, const void* h, const float* mean,
+                                       const float* rstd, const float* gamma, const float* beta, void* dh, void* dx_pool, float* dgamma,
+                                       float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype, float p_drop,
+                                       uint64_t seed, void* stream) {
+    SPV_CHECK(rows > 0 && spv_tail_ln_supported(n, k_in, dtype), "spv_spectre_tail_ln_bwd: unsupported shape %d -> %d / dtype %d", k_in, n, dtype);
+    SPV_CHECK(dout2 && f3 && res && mean2 && rstd2 && gamma2 && ds && dgamma2 && dbeta2 && h && mean && rstd && gamma && beta && dh && dx_pool &&
+                  dgamma && dbeta && dbias && partials,
+              "spv_spectre_tail_ln_bwd: null pointer");
+    const int bfl = dtype == SPV_BF16;
+    TailLn2 ln{res, gamma2, nullptr, nullptr, const_cast<float*>(mean2), const_cast<float*>(rstd2), dout2, f3, ds};
+    const int lwgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
+    const size_t lds = (size_t)RW * 5 * n * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bfl) hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, true, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln);
+    else hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, false, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln);
+    SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd");
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(5 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, lwgs, 5, n, dgamma2, dbeta2);
+    SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd(fold)");
     return 0;
 }
 

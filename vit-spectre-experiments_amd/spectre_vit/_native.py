@@ -31,6 +31,10 @@ SIGNATURES = {
     "spv_spectre_tail_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i,
                              c_i, c_f, c_u64, c_vp, c_vp],
     "spv_rowop_partial_floats": [c_i],
+    "spv_tail_ln_supported": [c_i, c_i, c_i],
+    "spv_tail_ln_partial_floats": [c_i],
+    "spv_spectre_tail_ln_fwd": [c_vp] * 13 + [c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],
+    "spv_spectre_tail_ln_bwd": [c_vp] * 20 + [c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],
     "spv_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_add_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
@@ -61,8 +65,8 @@ SIGNATURES = {
     "spv_axpby": [c_vp, c_vp, c_vp, c_f, c_f, c_i64, c_i, c_vp],
 }
 _RESTYPES = {"spv_last_error": ctypes.c_char_p, "spv_rowop_partial_floats": c_i64, "spv_fnet_workspace_floats": c_i64,
-             "spv_fnet_twiddle_floats": c_i64}
-_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported"}
+             "spv_fnet_twiddle_floats": c_i64, "spv_tail_ln_partial_floats": c_i64}
+_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_tail_ln_supported"}
 
 _lib = None
 

@@ -887,18 +887,54 @@ class FFResidualFn(torch.autograd.Function):
         if not x2d.is_contiguous():
             x2d = x2d.contiguous()
         f1, s1 = _sl_forward(x2d, w1, b1, g1, be1, p_drop, False)
+        ctx.shape = shape
+        n3, k3 = w3.shape
+        if _native.call("spv_tail_ln_supported", n3, k3, _dt(f1)):
+            # linear3's GEMM, then ONE row kernel: LayerNorm/GELU/pooled skip/dropout of the SpectreLinear tail, + x1, LayerNorm-2
+            rows, dt, dev = f1.shape[0], f1.dtype, f1.device
+            wc3, wt3 = _shadows.get(w3, dt)
+            h3 = torch.empty((rows, n3), dtype=dt, device=dev)
+            _gemm(f1, wc3, b3, h3, rows, n3, k3, k3, k3, n3)
+            f3 = torch.empty_like(h3)
+            out = torch.empty_like(h3)
+            mean3, rstd3, mean2, rstd2 = (torch.empty((rows,), dtype=torch.float32, device=dev) for _ in range(4))
+            seed = _new_seed() if p_drop > 0.0 else 0
+            _native.call("spv_spectre_tail_ln_fwd", _p(h3), _p(f1), _p(g3), _p(be3), _p(f3), _p(mean3), _p(rstd3), _p(x2d), _p(n2w),
+                         _p(n2b), _p(out), _p(mean2), _p(rstd2), rows, n3, k3, _dt(h3), float(p_drop), seed, _stream())
+            s3 = (f1, h3, mean3, rstd3, g3, be3, wt3, (_sink(w3), _sink(b3), _sink(g3), _sink(be3)), rows, n3, k3, float(p_drop), seed)
+            ctx.saved = (s1, s3, ("fused", f3, x2d, mean2, rstd2, n2w, (_sink(n2w), _sink(n2b))))
+            return out.reshape(shape)
         f3, s3 = _sl_forward(f1, w3, b3, g3, be3, p_drop, False)
         out, sn = _addln_forward(f3, x2d, n2w, n2b, 1)
         ctx.saved = (s1, s3, sn)
-        ctx.shape = shape
         return out.reshape(shape)
 
     @staticmethod
     def backward(ctx, dout):
         s1, s3, sn = ctx.saved
-        rows, n = sn[6], sn[7]
-        ds, dn2w, dn2b = _addln_backward(dout.reshape(rows, n), sn)      # d(x1 + f3)
-        df1, dw3, db3, dg3, dbe3 = _sl_backward(ds, s3, True)
+        if isinstance(sn[0], str):  # ("fused", ...): LayerNorm-2 backward inside the linear3 tail backward
+            _, f3, x1, mean2, rstd2, n2w, sinks2 = sn
+            f1, h3, mean3, rstd3, g3, be3, wt3, sinks3, rows, n, k, p_drop, seed = s3
+            dev = f1.device
+            d2 = dout.reshape(rows, n)
+            if not d2.is_contiguous():
+                d2 = d2.contiguous()
+            ds = torch.empty_like(f3)
+            dh3 = torch.empty_like(h3)
+            df1 = torch.empty_like(f1)
+            s_w, s_b, s_g, s_be = sinks3
+            dg3, dbe3, db3 = _grad_buf(s_g, (n,), dev), _grad_buf(s_be, (n,), dev), _grad_buf(s_b, (n,), dev)
+            dn2w, dn2b = _grad_buf(sinks2[0], (n,), dev), _grad_buf(sinks2[1], (n,), dev)
+            partials = torch.empty((_native.call("spv_tail_ln_partial_floats", n),), dtype=torch.float32, device=dev)
+            _native.call("spv_spectre_tail_ln_bwd", _p(d2), _p(f3), _p(x1), _p(mean2), _p(rstd2), _p(n2w), _p(ds), _p(dn2w), _p(dn2b),
+                         _p(h3), _p(mean3), _p(rstd3), _p(g3), _p(be3), _p(dh3), _p(df1), _p(dg3), _p(dbe3), _p(db3), _p(partials),
+                         rows, n, k, _dt(h3), p_drop, seed, _stream())
+            dw3 = _weight_grad(dh3, f1, rows, n, k, s_w)
+            _gemm(dh3, wt3, None, df1, rows, k, n, n, wt3.shape[1], k, accumulate=1)
+        else:
+            rows, n = sn[6], sn[7]
+            ds, dn2w, dn2b = _addln_backward(dout.reshape(rows, n), sn)      # d(x1 + f3)
+            df1, dw3, db3, dg3, dbe3 = _sl_backward(ds, s3, True)
         dx1, dw1, db1, dg1, dbe1 = _sl_backward(df1, s1, True, dx_add=ds)  # + the residual path, folded in
         join_side_stream()
         return dx1.reshape(ctx.shape), dw1, db1, dg1, dbe1, dw3, db3, dg3, dbe3, dn2w, dn2b, None
