@@ -80,10 +80,36 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__
     }
 }
 
+// mask(i) = hash(key(i >> 12), i & 4095): 8 consecutive elements per thread share the block key and four pair hashes
+// (16-byte bf16 / 2 x 16-byte fp32 accesses); the scalar form spent three hashes on every element
 __global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t n, float p,
                                                       uint64_t seed, int bf) {
     const float inv_keep = 1.0f / (1.0f - p);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    const int64_t n8 = n >> 3;
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n8; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = v << 3;
+        const unsigned key = dropout_row_key(seed, (uint64_t)i >> 12);
+        const unsigned c0 = (unsigned)(i & 4095);
+        float sc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sc[u] = dropout_scale(key, c0 + u, p, inv_keep);
+        if (bf) {
+            const uint4 t = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(x) + i);
+            const unsigned w[4] = {t.x, t.y, t.z, t.w};
+            unsigned o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                o[u] = (unsigned)f2bf(__uint_as_float(w[u] << 16) * sc[2 * u]) | ((unsigned)f2bf(__uint_as_float(w[u] & 0xffff0000u) * sc[2 * u + 1]) << 16);
+            *reinterpret_cast<uint4*>(static_cast<bf16_t*>(y) + i) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(x) + i);
+            const float4 b = *reinterpret_cast<const float4*>(static_cast<const float*>(x) + i + 4);
+            *reinterpret_cast<float4*>(static_cast<float*>(y) + i) = make_float4(a.x * sc[0], a.y * sc[1], a.z * sc[2], a.w * sc[3]);
+            *reinterpret_cast<float4*>(static_cast<float*>(y) + i + 4) = make_float4(b.x * sc[4], b.y * sc[5], b.z * sc[6], b.w * sc[7]);
+        }
+    }
+    // ragged tail (n not a multiple of 8): scalar
+    for (int64_t i = (n8 << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         st_any(y, (size_t)i, bf, ld_any(x, (size_t)i, bf) *
                                      dropout_scale(dropout_row_key(seed, (uint64_t)i >> 12), (unsigned)(i & 4095), p, inv_keep));
 }
@@ -205,7 +231,8 @@ extern "C" int spv_dropout(const void* x, void* y, int64_t n, float p, uint64_t 
     SPV_CHECK(p >= 0.0f && p < 1.0f, "spv_dropout: p=%f", p);
     SPV_CHECK(dtype == SPV_F32 || dtype == SPV_BF16, "spv_dropout: bad dtype");
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks(n)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, p, seed,
+    SPV_CHECK(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "spv_dropout: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(dropout_kernel, dim3(ew_blocks((n + 7) / 8)), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, n, p, seed,
                        dtype == SPV_BF16);
     SPV_LAUNCH_CHECK("spv_dropout");
     return 0;
