@@ -68,6 +68,35 @@ def test_gemm_nt(ops, dtype, M, N, K, splits):
     check(C2, a @ b.T + c2, TOL[dtype], "gemm accumulate")
 
 
+@pytest.mark.parametrize("M,N,K", [(33280, 768, 512), (33280, 512, 768), (33270, 256, 128), (20000, 512, 384), (33280, 1024, 256),
+                                   (94203, 512, 128)])
+def test_gemm_nt_strip_kernel(ops, M, N, K):
+    """The one-workgroup-per-CU strip kernel (bf16 out, N % 256 == 0, K % 128 == 0, M >= 8192) against the 128 x 128 kernel of
+    the same library (fp32 out never takes the strip path): same MFMA order along K, so the bf16 results must be the
+    rounding of the fp32 ones bit for bit -- uneven row shares, the extra block, the masked last rows, bias, accumulate."""
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = (torch.randn((M, K), generator=g) * 0.5).to(dev()).to(torch.bfloat16)
+    B = (torch.randn((N, K), generator=g) * 0.1).to(dev()).to(torch.bfloat16)
+    bias = torch.randn((N,), generator=g).to(dev())
+    C32 = torch.empty((M, N), dtype=torch.float32, device=dev())
+    ops._gemm(A, B, bias, C32, M, N, K, K, K, N, 0, 1, None)
+    # independent reference on a sample of rows (fp64)
+    rows = torch.tensor([0, 1, 31, 32, 255, 256, 287, 288, 1000, M // 2, M - 33, M - 2, M - 1])
+    ref = A[rows].double().cpu().numpy() @ B.double().cpu().numpy().T + bias.double().cpu().numpy()
+    check(C32[rows], ref, 1e-4, "fp32-out reference kernel")
+    C = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device=dev())  # one guard row behind the output
+    ops._gemm(A, B, bias, C, M, N, K, K, K, N, 0, 1, None)
+    assert torch.equal(C[:M], C32.to(torch.bfloat16)), "strip kernel differs from the rounded fp32 result"
+    assert bool((C[M] == 7.0).all()), "strip kernel wrote past the last row"
+    # accumulate into an existing bf16 C (the data-gradient GEMMs of the layer): (acc + 0) + old, one rounding
+    C0 = torch.randn((M, N), generator=g).to(dev()).to(torch.bfloat16)
+    C2 = C0.clone()
+    ops._gemm(A, B, None, C2, M, N, K, K, K, N, 1, 1, None)
+    C32b = torch.empty((M, N), dtype=torch.float32, device=dev())
+    ops._gemm(A, B, None, C32b, M, N, K, K, K, N, 0, 1, None)
+    assert torch.equal(C2, (C32b + C0.float()).to(torch.bfloat16)), "strip kernel accumulate differs"
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(128, 128, 64, 1), (768, 512, 33280, 12), (104, 48, 1000, 3), (512, 8192, 2600, 2),
                                           (8, 16, 40, 1), (264, 136, 4100, 5)])
 def test_gemm_tn(ops, M, N, K, splits):

@@ -1,0 +1,616 @@
+// gemm_big_lab.hip -- development bench of the one-round NT GEMM ("big tile") against the shipped 128 x 128 kernel.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_big_lab.hip -o tools/_build/gemm_big_lab && tools/_build/gemm_big_lab
+// Idea: the layer GEMMs (33280 x 768 x 512, 33280 x 512 x 768) are 1560 / 1040 tiles of 128 x 128 on 768 workgroup
+// slots: 2.03 / 1.35 dispatch rounds, and a 128 x 128 tile needs as many L1->LDS bytes per flop as the CU can move.
+// Here ONE workgroup per CU (8 waves) owns a 256-column strip x an uneven run of 32-row blocks, so that the grid is
+// exactly <= 256 workgroups with the same work (+- one block) each.
+#include "../vit-spectre-experiments_amd/csrc/spv_gemm.hip"
+#include "../vit-spectre-experiments_amd/csrc/spv_misc.hip"
+
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+// MB: 32-row blocks per wave row (2 wave rows x 4 wave columns); a sub-tile is 2*MB blocks (+1 optional block whose
+// 32 x 256 strip is shared out as one 32 x 32 block per wave).
+template <int MB, int ABL>
+__global__ __launch_bounds__(512) void big_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                  const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N, int K,
+                                                  int lda, int ldb, int ldc, int nstrips, int base, int rem, int nwg) {
+    constexpr int TM = 64 * MB;
+    constexpr int STAGE = (TM + 32 + 256) * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int g = id / nstrips, strip = id % nstrips;
+    int blk0 = g * base + min(g, rem);
+    int cnt = base + (g < rem ? 1 : 0);
+    const int n0 = strip * 256;
+    const int nkt = K / 64;
+
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int R = 8 * (wave * 4 + t) + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        bsrc[t] = B + (size_t)(n0 + R) * ldb + c * 8;
+    }
+    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 1) & 7;
+    const int fa_off = (wm * 32 * MB + frow) * 128;
+    const int fax_off = (TM + frow) * 128;
+    const int fb_off = (TM + 32 + wn * 64 + frow) * 128;
+    const int fbx_off = (TM + 32 + wave * 32 + frow) * 128;
+
+    while (cnt > 0) {
+        const int take = (cnt % (2 * MB) != 0 && cnt >= 2 * MB + 1) ? 2 * MB + 1 : min(2 * MB, cnt);
+        const bool extra = take == 2 * MB + 1;
+        const int m0 = blk0 * 32;
+        const int mlim = min(M, (blk0 + take) * 32);
+        const bf16_t* asrc[MB];
+        const bf16_t* axsrc;
+#pragma unroll
+        for (int t = 0; t < MB; ++t) {
+            const int R = 8 * (wave * MB + t) + (lane >> 3);
+            const int c = (lane & 7) ^ ((R >> 1) & 7);
+            asrc[t] = A + (size_t)min(m0 + R, M - 1) * lda + c * 8;
+        }
+        {
+            const int R = TM + 8 * (wave & 3) + (lane >> 3);
+            const int c = (lane & 7) ^ ((R >> 1) & 7);
+            axsrc = A + (size_t)min(m0 + R, M - 1) * lda + c * 8;
+        }
+        auto stage = [&](int buf, int k0) {
+            unsigned char* sa = smem + buf * STAGE + wave * MB * 1024;
+            unsigned char* sb = smem + buf * STAGE + (TM + 32) * 128 + wave * 4 * 1024;
+#pragma unroll
+            for (int t = 0; t < MB; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[t] + k0),
+                                                 (__attribute__((address_space(3))) void*)(sa + t * 1024), 16, 0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[t] + k0),
+                                                 (__attribute__((address_space(3))) void*)(sb + t * 1024), 16, 0, 0);
+            if (extra && wave < 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(axsrc + k0),
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * STAGE + TM * 128 + wave * 1024), 16,
+                                                 0, 0);
+        };
+
+        f32x16 acc[MB][2], accx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accx[r] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                acc[i][0][r] = 0.0f;
+                acc[i][1][r] = 0.0f;
+            }
+        }
+        stage(0, 0);
+        for (int t = 0; t < nkt; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < nkt) stage((t + 1) & 1, (t + 1) * 64);
+            const unsigned char* sp = smem + (t & 1) * STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ch = ((ks * 2 + fh) ^ swz) * 16;
+                bf16x8 a[MB], b[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) b[f] = *reinterpret_cast<const bf16x8*>(sp + fb_off + f * 32 * 128 + ch);
+#pragma unroll
+                for (int f = 0; f < MB; ++f) a[f] = *reinterpret_cast<const bf16x8*>(sp + fa_off + f * 32 * 128 + ch);
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                if (extra) {
+                    const bf16x8 ax = *reinterpret_cast<const bf16x8*>(sp + fax_off + ch);
+                    const bf16x8 bx = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax, bx, accx, 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the operand stages: they become the epilogue staging area
+        if (!(ABL & 1)) {
+            float* st = reinterpret_cast<float*>(smem + wave * 9216);
+            constexpr int SLD = 68;
+            auto emit = [&](int row0, int col0, int ncol8) {
+                // st holds 32 rows x (8 * ncol8) columns
+                for (int q = lane; q < 32 * ncol8; q += 64) {
+                    const int lr = q / ncol8, c8 = q % ncol8;
+                    const int row = row0 + lr, col = col0 + c8 * 8;
+                    if (row >= mlim) continue;
+                    const float4 lo = *reinterpret_cast<const float4*>(st + lr * SLD + c8 * 8);
+                    const float4 hi = *reinterpret_cast<const float4*>(st + lr * SLD + c8 * 8 + 4);
+                    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    if (bias != nullptr) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(bias + col), b1 = *reinterpret_cast<const float4*>(bias + col + 4);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                    uint4 o;
+                    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+                    o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                    *reinterpret_cast<uint4*>(C + (size_t)row * ldc + col) = o;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + j * 32 + (lane & 31)] = acc[i][j][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                emit(m0 + wm * 32 * MB + i * 32, n0 + wn * 64, 8);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
+            if (extra) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + (lane & 31)] = accx[r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                emit(m0 + TM, n0 + wave * 32, 4);
+            }
+        } else {
+            float s = accx[0];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][0][r] + acc[i][1][r];
+            if (s == 1234.5678f) C[0] = 1;
+        }
+        blk0 += take;
+        cnt -= take;
+        if (cnt > 0) __syncthreads();  // the staging area goes back to the DMA
+    }
+}
+
+template <int MB, int ABL>
+static int launch_big(const bf16_t* A, const bf16_t* B, const float* bias, bf16_t* C, int M, int N, int K, hipStream_t st) {
+    const int nstrips = N / 256;
+    const int nblk = (M + 31) / 32;
+    int groups = 256 / nstrips;
+    if (groups > nblk) groups = nblk;
+    const int base = nblk / groups, rem = nblk % groups;
+    const int nwg = groups * nstrips;
+    hipLaunchKernelGGL((big_kernel<MB, ABL>), dim3(nwg), dim3(512), 0, st, A, B, bias, C, M, N, K, K, K, N, nstrips, base, rem, nwg);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+__device__ __forceinline__ void vmwait_rt(int n) {
+    switch (n) {
+#define VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        VMW(1) VMW(2) VMW(3) VMW(4) VMW(5) VMW(6) VMW(7) VMW(8) VMW(9) VMW(10) VMW(11) VMW(12) VMW(13) VMW(14) VMW(15) VMW(16)
+        VMW(17) VMW(18) VMW(19) VMW(20) VMW(21) VMW(22) VMW(23) VMW(24) VMW(25) VMW(26) VMW(27) VMW(28) VMW(29) VMW(30)
+#undef VMW
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// v2: the K-tile pipeline runs on across the sub-tiles of a workgroup (the next sub-tile's first K-tile -- and second,
+// when the epilogue has its own LDS -- is in flight before the epilogue's stores are issued), and the waits behind an
+// epilogue are counted so that they cover the LDS-DMA but not the younger stores (vmcnt retires in issue order).
+template <int MB, int ABL, int IL, int ST, int PR>
+__global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                   const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N, int K,
+                                                   int lda, int ldb, int ldc, int nstrips, int base, int rem, int nwg) {
+    constexpr int TM = 64 * MB;
+    constexpr int STAGE = (TM + 32 + 256) * 128;
+    constexpr bool PRE1 = MB <= 3;                   // room for a separate epilogue staging area
+    constexpr int EPI = 8 * 4352;                    // 8 waves x [16 rows][68] floats
+    constexpr int EPI_OFF = PRE1 ? 2 * STAGE : STAGE;
+    constexpr int BIAS_OFF = PRE1 ? 2 * STAGE + EPI : 2 * STAGE;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[BIAS_OFF + 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int g = id / nstrips, strip = id % nstrips;
+    int blk0 = g * base + min(g, rem);
+    int cnt = base + (g < rem ? 1 : 0);
+    const int n0 = strip * 256;
+    const int nkt = K / 64;
+    if (PR == 1 && wm == 0) __builtin_amdgcn_s_setprio(2);
+    if (PR == 3 && wm == 1) __builtin_amdgcn_s_setprio(2);
+
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int R = 8 * (wave * 4 + t) + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        bsrc[t] = B + (size_t)(n0 + R) * ldb + c * 8;
+    }
+    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 1) & 7;
+    const int fa_off = (wm * 32 * MB + frow) * 128;
+    const int fax_off = (TM + frow) * 128;
+    const int fb_off = (TM + 32 + wn * 64 + frow) * 128;
+    const int fbx_off = (TM + 32 + wave * 32 + frow) * 128;
+    // the strip's 256 bias values live in LDS (first read behind the K loop's barriers)
+    float* sbias = reinterpret_cast<float*>(smem + BIAS_OFF);
+    if (tid < 256) sbias[tid] = bias ? bias[n0 + tid] : 0.0f;
+    const float* bv = sbias + wn * 64 + (lane & 7) * 8;
+    const float* bvx = sbias + wave * 32 + (lane & 3) * 8;
+
+    const bf16_t* asrc[MB];
+    const bf16_t* axsrc;
+    int s_m0, s_mlim, s_take;
+    bool s_extra;
+    auto setup = [&]() {  // descriptors + source pointers of the sub-tile starting at blk0 (cnt blocks left)
+        s_take = (cnt % (2 * MB) != 0 && cnt >= 2 * MB + 1) ? 2 * MB + 1 : min(2 * MB, cnt);
+        s_extra = s_take == 2 * MB + 1;
+        s_m0 = blk0 * 32;
+        s_mlim = min(M, (blk0 + s_take) * 32);
+#pragma unroll
+        for (int t = 0; t < MB; ++t) {
+            const int R = 8 * (wave * MB + t) + (lane >> 3);
+            const int c = (lane & 7) ^ ((R >> 1) & 7);
+            asrc[t] = A + (size_t)min(s_m0 + R, M - 1) * lda + c * 8;
+        }
+        const int R = TM + 8 * (wave & 3) + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        axsrc = A + (size_t)min(s_m0 + R, M - 1) * lda + c * 8;
+        blk0 += s_take;
+        cnt -= s_take;
+    };
+    auto stage = [&](int buf, int k0) {
+        unsigned char* sa = smem + buf * STAGE + wave * MB * 1024;
+        unsigned char* sb = smem + buf * STAGE + (TM + 32) * 128 + wave * 4 * 1024;
+#pragma unroll
+        for (int t = 0; t < MB; ++t)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[t] + k0),
+                                             (__attribute__((address_space(3))) void*)(sa + t * 1024), 16, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[t] + k0),
+                                             (__attribute__((address_space(3))) void*)(sb + t * 1024), 16, 0, 0);
+        if (s_extra && (IL == 3 || wave < 4))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(axsrc + k0),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE + TM * 128 + (wave & 3) * 1024), 16, 0, 0);
+    };
+
+    // one LDS-DMA piece of a K-tile (compile-time index: A pieces, B pieces, then the optional extra-block piece)
+    auto piece = [&](auto ptag, int buf, int k0) __attribute__((always_inline)) {
+        constexpr int P = decltype(ptag)::value;
+        if constexpr (P < MB) {
+            if constexpr (!(ABL & 4))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[P < MB ? P : 0] + k0),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (wave * MB + P) * 1024), 16, 0, 0);
+        } else if constexpr (P < MB + 4) {
+            if constexpr (!(ABL & 2))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[P >= MB && P < MB + 4 ? P - MB : 0] + k0),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (TM + 32) * 128 + (wave * 4 + P - MB) * 1024), 16, 0, 0);
+        } else if constexpr (P == MB + 4) {
+            if (!(ABL & 4) && s_extra && (IL == 3 || wave < 4))
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(axsrc + k0),
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * STAGE + TM * 128 + (wave & 3) * 1024), 16, 0, 0);
+        }
+    };
+    constexpr int PPK = (MB + 5 + 2) / 3;  // pieces issued behind each of the first three k-steps' MFMAs
+
+    setup();
+    stage(0, 0);
+    int pend = 0;          // epilogue stores issued after the newest staged K-tile
+    bool kt1 = false;      // the second K-tile of the current sub-tile was staged ahead of the previous epilogue
+    while (true) {
+        const int c_m0 = s_m0, c_mlim = s_mlim, c_take = s_take;
+        const bool extra = s_extra;
+        const bool more = cnt > 0;
+        const int pieces = MB + 4 + ((extra && (IL == 3 || wave < 4)) ? 1 : 0);
+        f32x16 acc[MB][2], accx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accx[r] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                acc[i][0][r] = 0.0f;
+                acc[i][1][r] = 0.0f;
+            }
+        }
+        for (int t = 0; t < nkt; ++t) {
+            if (t == 0) vmwait_rt(kt1 ? pend + pieces : pend);
+            else if (t == 1 && kt1) vmwait_rt(pend);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            bool dma = false;
+            int dbuf = 0, dk0 = 0;
+            if (t + 1 < nkt) {
+                if (!(t == 0 && kt1)) { dma = true; dbuf = (t + 1) & 1; dk0 = (t + 1) * 64; }
+            } else if (more) {
+                setup();       // the descriptors now describe the NEXT sub-tile
+                dma = true;
+            }
+            if (!IL && dma) stage(dbuf, dk0);
+            if (IL == 3) dma = dma && true;
+            const unsigned char* sp = smem + (t & 1) * STAGE;
+            auto kstep = [&](auto kstag) {
+                constexpr int ks = decltype(kstag)::value;
+                const int ch = ((ks * 2 + fh) ^ swz) * 16;
+                bf16x8 a[MB], b[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) b[f] = *reinterpret_cast<const bf16x8*>(sp + fb_off + f * 32 * 128 + ch);
+#pragma unroll
+                for (int f = 0; f < MB; ++f) a[f] = *reinterpret_cast<const bf16x8*>(sp + fa_off + f * 32 * 128 + ch);
+                if constexpr (PR == 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                if constexpr (PR == 2) __builtin_amdgcn_s_setprio(0);
+                if (extra) {
+                    const bf16x8 ax = *reinterpret_cast<const bf16x8*>(sp + fax_off + ch);
+                    const bf16x8 bx = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax, bx, accx, 0, 0, 0);
+                }
+                if constexpr (IL != 0 && ks < 3) {
+                    if (dma) {
+                        piece(std::integral_constant<int, ks * PPK + 0>{}, dbuf, dk0);
+                        if constexpr (PPK > 1) piece(std::integral_constant<int, ks * PPK + 1>{}, dbuf, dk0);
+                        if constexpr (PPK > 2) piece(std::integral_constant<int, ks * PPK + 2>{}, dbuf, dk0);
+                    }
+                    if constexpr (IL == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if constexpr (IL != 3) {
+                kstep(std::integral_constant<int, 0>{});
+                kstep(std::integral_constant<int, 1>{});
+                kstep(std::integral_constant<int, 2>{});
+                kstep(std::integral_constant<int, 3>{});
+            } else {
+                // straight-line K-tile: fragments of k-step s+1 are read while the MFMAs of k-step s run; the DMA pieces of
+                // the next K-tile go out behind the MFMAs of the first three k-steps.  EXTRA / DMA are compile-time here
+                // (branches inside would fence the scheduler).
+                auto ktile = [&](auto extra_tag, auto dma_tag) __attribute__((always_inline)) {
+                    constexpr bool EXTRA = decltype(extra_tag)::value, DMA = decltype(dma_tag)::value;
+                    struct Frag { bf16x8 a[MB], b[2], ax, bx; };
+                    Frag f0, f1;
+                    auto load = [&](auto kstag, Frag& f) __attribute__((always_inline)) {
+                        constexpr int ks = decltype(kstag)::value;
+                        const int ch = ((ks * 2 + fh) ^ swz) * 16;
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) f.b[q] = *reinterpret_cast<const bf16x8*>(sp + fb_off + q * 32 * 128 + ch);
+#pragma unroll
+                        for (int q = 0; q < MB; ++q) f.a[q] = *reinterpret_cast<const bf16x8*>(sp + fa_off + q * 32 * 128 + ch);
+                        if constexpr (EXTRA) {
+                            f.ax = *reinterpret_cast<const bf16x8*>(sp + fax_off + ch);
+                            f.bx = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
+                        }
+                    };
+                    auto mm = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int i = 0; i < MB; ++i)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+                        if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ax, f.bx, accx, 0, 0, 0);
+                    };
+                    auto dmas = [&](auto kstag) __attribute__((always_inline)) {
+                        constexpr int ks = decltype(kstag)::value;
+                        if constexpr (DMA) {
+                            piece(std::integral_constant<int, ks * PPK + 0>{}, dbuf, dk0);
+                            if constexpr (PPK > 1) piece(std::integral_constant<int, ks * PPK + 1>{}, dbuf, dk0);
+                            if constexpr (PPK > 2) piece(std::integral_constant<int, ks * PPK + 2>{}, dbuf, dk0);
+                        }
+                    };
+                    load(std::integral_constant<int, 0>{}, f0);
+                    load(std::integral_constant<int, 1>{}, f1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(f0);
+                    dmas(std::integral_constant<int, 0>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    load(std::integral_constant<int, 2>{}, f0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(f1);
+                    dmas(std::integral_constant<int, 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    load(std::integral_constant<int, 3>{}, f1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(f0);
+                    dmas(std::integral_constant<int, 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(f1);
+                };
+                if (extra) {
+                    if (dma) ktile(std::true_type{}, std::true_type{});
+                    else ktile(std::true_type{}, std::false_type{});
+                } else {
+                    if (dma) ktile(std::false_type{}, std::true_type{});
+                    else ktile(std::false_type{}, std::false_type{});
+                }
+            }
+        }
+        kt1 = false;
+        if (PRE1 && more) {
+            __builtin_amdgcn_s_barrier();   // every wave is done with buffer 1
+            stage(1, 64);
+            kt1 = true;
+        }
+        if (!PRE1) __syncthreads();         // the epilogue stages through buffer 1
+        pend = 0;
+        if (!(ABL & 1)) {
+            float* st = reinterpret_cast<float*>(smem + EPI_OFF + wave * 4352);
+            constexpr int SLD = 68;
+            const bool exact = c_take >= 2 * MB && c_mlim == c_m0 + c_take * 32;
+            auto pack_store = [&](const float* v, const float* bb, int row, int col) {
+                uint4 o;
+                o.x = (unsigned)f2bf(v[0] + bb[0]) | ((unsigned)f2bf(v[1] + bb[1]) << 16);
+                o.y = (unsigned)f2bf(v[2] + bb[2]) | ((unsigned)f2bf(v[3] + bb[3]) << 16);
+                o.z = (unsigned)f2bf(v[4] + bb[4]) | ((unsigned)f2bf(v[5] + bb[5]) << 16);
+                o.w = (unsigned)f2bf(v[6] + bb[6]) | ((unsigned)f2bf(v[7] + bb[7]) << 16);
+                uint4* dst = reinterpret_cast<uint4*>(C + (size_t)row * ldc + col);
+                if constexpr (ST == 0) *dst = o;
+                else {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 ov = {o.x, o.y, o.z, o.w};
+                    if constexpr (ST == 1) __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(dst));
+                    else if constexpr (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+                    else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(ov) : "memory");
+                }
+            };
+            // one half (16 rows) of a 32 x 64 accumulator pair: 2 stores per lane
+            auto emit64 = [&](int row0, bool masked) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int q = lane + 64 * it, lr = q >> 3, c8 = q & 7;
+                    const float4 lo = *reinterpret_cast<const float4*>(st + lr * SLD + c8 * 8);
+                    const float4 hi = *reinterpret_cast<const float4*>(st + lr * SLD + c8 * 8 + 4);
+                    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    if (!masked || row0 + lr < c_mlim) pack_store(v, bv, row0 + lr, n0 + wn * 64 + c8 * 8);
+                }
+            };
+            auto emit32 = [&](int row0, bool masked) {  // 16 rows x 32 columns: 1 store per lane
+                const int lr = lane >> 2, c8 = lane & 3;
+                const float4 lo = *reinterpret_cast<const float4*>(st + lr * SLD + c8 * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(st + lr * SLD + c8 * 8 + 4);
+                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (!masked || row0 + lr < c_mlim) pack_store(v, bvx, row0 + lr, n0 + wave * 32 + c8 * 8);
+            };
+            auto run = [&](auto masked_tag) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int r = 0; r < 8; ++r)
+                                st[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + j * 32 + (lane & 31)] = acc[i][j][8 * h + r];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        emit64(c_m0 + wm * 32 * MB + i * 32 + 16 * h, MASKED);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    }
+                if (extra) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + (lane & 31)] = accx[8 * h + r];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        emit32(c_m0 + TM + 16 * h, MASKED);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    }
+                }
+            };
+            if (exact) {
+                run(std::false_type{});
+                pend = 4 * MB + (extra ? 2 : 0);
+            } else {
+                run(std::true_type{});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            float s = accx[0];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += acc[i][0][r] + acc[i][1][r];
+            if (s == 1234.5678f) C[0] = 1;
+        }
+        if (!more) break;
+    }
+}
+
+template <int MB, int ABL, int IL = 0, int ST = 0, int PR = 0>
+static int launch_big2(const bf16_t* A, const bf16_t* B, const float* bias, bf16_t* C, int M, int N, int K, hipStream_t st) {
+    const int nstrips = N / 256;
+    const int nblk = (M + 31) / 32;
+    int groups = 256 / nstrips;
+    if (groups > nblk) groups = nblk;
+    const int base = nblk / groups, rem = nblk % groups;
+    const int nwg = groups * nstrips;
+    hipLaunchKernelGGL((big2_kernel<MB, ABL, IL, ST, PR>), dim3(nwg), dim3(512), 0, st, A, B, bias, C, M, N, K, K, K, N, nstrips, base, rem, nwg);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+template <typename F>
+static float time_us(F&& f, int iters) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) f();
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) f();
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return ms * 1e3f / iters;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 33280, N = argc > 2 ? atoi(argv[2]) : 768, K = argc > 3 ? atoi(argv[3]) : 512;
+    const int rounds = argc > 4 ? atoi(argv[4]) : 5;
+    bf16_t *A, *B, *C, *Cref;
+    float* bias;
+    hipMalloc(&A, (size_t)M * K * 2);
+    hipMalloc(&B, (size_t)N * K * 2);
+    hipMalloc(&C, (size_t)M * N * 2);
+    hipMalloc(&Cref, (size_t)M * N * 2);
+    hipMalloc(&bias, N * 4);
+    std::vector<bf16_t> h((size_t)M * K), hb((size_t)N * K);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s; };
+    auto tobf = [](float f) { unsigned u; memcpy(&u, &f, 4); return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1)) >> 16); };
+    for (auto& v : h) v = tobf(((int)(rnd() >> 8 & 0xffff) - 32768) / 32768.0f);
+    for (auto& v : hb) v = tobf(((int)(rnd() >> 8 & 0xffff) - 32768) / 32768.0f * 0.05f);
+    std::vector<float> hbias(N);
+    for (auto& v : hbias) v = ((int)(rnd() >> 8 & 0xffff) - 32768) / 32768.0f;
+    hipMemcpy(A, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(B, hb.data(), hb.size() * 2, hipMemcpyHostToDevice);
+    hipMemcpy(bias, hbias.data(), N * 4, hipMemcpyHostToDevice);
+    const double gf = 2.0 * M * N * K * 1e-6;
+    printf("M=%d N=%d K=%d\n", M, N, K);
+    // reference = the shipped kernel
+    if (spv_gemm_nt(A, B, bias, Cref, M, N, K, K, K, N, SPV_BF16, SPV_BF16, 0, 1, nullptr, nullptr)) {
+        printf("reference launch failed: %s\n", spv_last_error());
+        return 1;
+    }
+    hipDeviceSynchronize();
+    std::vector<bf16_t> href((size_t)M * N), hc((size_t)M * N);
+    hipMemcpy(href.data(), Cref, href.size() * 2, hipMemcpyDeviceToHost);
+    auto compare = [&](const char* what) {
+        hipDeviceSynchronize();
+        hipMemcpy(hc.data(), C, hc.size() * 2, hipMemcpyDeviceToHost);
+        size_t bad = 0, first = 0;
+        for (size_t i = 0; i < hc.size(); ++i)
+            if (hc[i] != href[i]) { if (!bad) first = i; ++bad; }
+        printf("  %-28s mismatching elements vs shipped kernel: %zu", what, bad);
+        if (bad) printf("  (first at row %zu col %zu)", first / N, first % N);
+        printf("\n");
+        fflush(stdout);
+    };
+#define CHECKV(MB, IL, ST, PR)                                        \
+    hipMemset(C, 0xff, (size_t)M * N * 2);                            \
+    launch_big2<MB, 0, IL, ST, PR>(A, B, bias, C, M, N, K, nullptr);  \
+    compare("big2 MB=" #MB " IL=" #IL " ST=" #ST " PR=" #PR);
+#define TIMEV(MB, ABL, IL, ST, PR) time_us([&] { launch_big2<MB, ABL, IL, ST, PR>(A, B, bias, C, M, N, K, nullptr); }, 20)
+    if (N == 768) {
+        CHECKV(3, 1, 2, 0) CHECKV(3, 1, 2, 1) CHECKV(3, 1, 2, 2) CHECKV(3, 1, 2, 3)
+        for (int r = 0; r < rounds; ++r) {
+            const float t0 = time_us([&] { spv_gemm_nt(A, B, bias, Cref, M, N, K, K, K, N, SPV_BF16, SPV_BF16, 0, 1, nullptr, nullptr); }, 20);
+            const float a = TIMEV(3, 0, 1, 2, 0), b = TIMEV(3, 0, 1, 2, 1), c = TIMEV(3, 0, 1, 2, 2), c3 = TIMEV(3, 0, 1, 2, 3), d = TIMEV(3, 1, 1, 2, 0), e = TIMEV(3, 1, 1, 2, 1), f = TIMEV(3, 1, 1, 2, 2);
+            printf("round %d: shipped %6.2f | MB=3 IL1+sc1 prio: none %6.2f  static %6.2f  pair %6.2f  static-rev %6.2f | no store: none %6.2f static %6.2f pair %6.2f\n", r, t0, a, b, c, c3, d, e, f);
+            fflush(stdout);
+        }
+    } else {
+        CHECKV(4, 1, 2, 0) CHECKV(4, 1, 2, 1) CHECKV(4, 1, 2, 2) CHECKV(4, 1, 2, 3)
+        for (int r = 0; r < rounds; ++r) {
+            const float t0 = time_us([&] { spv_gemm_nt(A, B, bias, Cref, M, N, K, K, K, N, SPV_BF16, SPV_BF16, 0, 1, nullptr, nullptr); }, 20);
+            const float a = TIMEV(4, 0, 1, 2, 0), b = TIMEV(4, 0, 1, 2, 1), c = TIMEV(4, 0, 1, 2, 2), c3 = TIMEV(4, 0, 1, 2, 3), d = TIMEV(4, 1, 1, 2, 0), e = TIMEV(4, 1, 1, 2, 1), f = TIMEV(4, 1, 1, 2, 2);
+            printf("round %d: shipped %6.2f | MB=4 IL1+sc1 prio: none %6.2f  static %6.2f  pair %6.2f  static-rev %6.2f | no store: none %6.2f static %6.2f pair %6.2f\n", r, t0, a, b, c, c3, d, e, f);
+            fflush(stdout);
+        }
+    }
+    return 0;
+}

@@ -15,6 +15,9 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+#include <type_traits>
+
 namespace {
 
 constexpr int BM = 128, BN = 128;
@@ -413,6 +416,345 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// NT contraction, strip kernel (bf16 in, bf16 out, N a multiple of 256, K of 128): the layer GEMMs of the training step
+// (33280 x 768 x 512 and 33280 x 512 x 768).  On the 128 x 128 kernels those are 1560 / 1040 tiles on 768 workgroup
+// slots (2.03 / 1.35 dispatch rounds, the last one nearly empty), and a 128 x 128 x 64 K-step moves as many bytes
+// L2 -> LDS as the CU can take in the time of its MFMAs (64 B/clk against 4096 flop/clk).  Here ONE 8-wave workgroup
+// per CU owns a 256-column strip of C and an uneven run of 32-row blocks (the host hands out ceil/floor shares, so the
+// grid is <= 256 workgroups with the same work +- one block):
+//   * a sub-tile is 2*MB row blocks x 256 columns (waves as 2 x 4, wave tile 32*MB x 64) plus an optional extra block
+//     whose 32 x 256 strip is shared out as one 32 x 32 accumulator per wave -- the +-1 block of the uneven shares
+//     costs every wave the same;
+//   * operands are staged by LDS-DMA in 64-deep K-tiles, two buffers, the pieces of K-tile t+1 issued behind the MFMAs
+//     of the first three k-steps of K-tile t (one burst stalls all 8 waves on the 64 B/clk L1 path);
+//   * the pipeline runs on across sub-tiles: the next sub-tile's first two K-tiles are in flight before the epilogue's
+//     stores are issued, and the waits behind an epilogue are COUNTED (vmcnt retires loads, LDS-DMA and stores in issue
+//     order), so they cover the DMA but not the younger stores;
+//   * C leaves through a wave-private fp32 LDS stage as 16-byte write-through (sc1) stores: plain stores leave the
+//     lines dirty in L2 and the end-of-kernel write-back is then serial (1-1.5 us per launch).
+// Measured (tools/gemm_big_lab.hip, bit-identical output): 31.5 vs 46 us at 33280 x 768 x 512, 29.5 vs 45 us at
+// 33280 x 512 x 768.
+__device__ __forceinline__ void vmwait_upto(int n) {
+    switch (n) {
+#define SPV_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+        SPV_VMW(1) SPV_VMW(2) SPV_VMW(3) SPV_VMW(4) SPV_VMW(5) SPV_VMW(6) SPV_VMW(7) SPV_VMW(8) SPV_VMW(9) SPV_VMW(10)
+        SPV_VMW(11) SPV_VMW(12) SPV_VMW(13) SPV_VMW(14) SPV_VMW(15) SPV_VMW(16) SPV_VMW(17) SPV_VMW(18) SPV_VMW(19) SPV_VMW(20)
+        SPV_VMW(21) SPV_VMW(22) SPV_VMW(23) SPV_VMW(24) SPV_VMW(25) SPV_VMW(26) SPV_VMW(27) SPV_VMW(28) SPV_VMW(29) SPV_VMW(30)
+#undef SPV_VMW
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int MB, bool ACC>
+__global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int K,
+                                                            int lda, int ldb, int ldc, int nstrips, int base, int rem, int nwg) {
+    constexpr int TM = 64 * MB;                       // rows of a sub-tile without the extra block
+    constexpr int STAGE = (TM + 32 + 256) * 128;      // one K-tile: A rows, extra A rows, B rows, 128 B (64 bf16) each
+    constexpr bool PRE1 = MB <= 3;                    // LDS left for an epilogue stage beside the two K-tile buffers
+    constexpr int EPI = 8 * 4352;                     // 8 waves x [16 rows][68] floats
+    constexpr int EPI_OFF = PRE1 ? 2 * STAGE : STAGE; // MB = 4: the epilogue stages through K-tile buffer 1
+    constexpr int BIAS_OFF = PRE1 ? 2 * STAGE + EPI : 2 * STAGE;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[BIAS_OFF + 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    // the strips of one row group sit on one XCD and run together: its A rows are fetched into that L2 once
+    const int id = xcd_remap(blockIdx.x, nwg);
+    const int g = id / nstrips, strip = id % nstrips;
+    int blk0 = g * base + min(g, rem);
+    int cnt = base + (g < rem ? 1 : 0);
+    const int n0 = strip * 256;
+    const int nkt = K / 64;
+
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int R = 8 * (wave * 4 + t) + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);    // the swizzle of gemm_nt_glds_kernel<., 128, .>
+        bsrc[t] = B + (size_t)(n0 + R) * ldb + c * 8;
+    }
+    const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 1) & 7;
+    const int fa_off = (wm * 32 * MB + frow) * 128;
+    const int fax_off = (TM + frow) * 128;
+    const int fb_off = (TM + 32 + wn * 64 + frow) * 128;
+    const int fbx_off = (TM + 32 + wave * 32 + frow) * 128;
+    float* sbias = reinterpret_cast<float*>(smem + BIAS_OFF);  // first read behind the K loop's barriers
+    if (tid < 256) sbias[tid] = bias ? bias[n0 + tid] : 0.0f;
+    const float* bv = sbias + wn * 64 + (lane & 7) * 8;
+    const float* bvx = sbias + wave * 32 + (lane & 3) * 8;
+
+    const bf16_t* asrc[MB];
+    const bf16_t* axsrc;
+    int s_m0, s_mlim, s_take;
+    bool s_extra;
+    auto setup = [&]() {  // descriptors + DMA source pointers of the sub-tile that starts at block blk0
+        s_take = (cnt % (2 * MB) != 0 && cnt >= 2 * MB + 1) ? 2 * MB + 1 : min(2 * MB, cnt);
+        s_extra = s_take == 2 * MB + 1;
+        s_m0 = blk0 * 32;
+        s_mlim = min(M, (blk0 + s_take) * 32);
+#pragma unroll
+        for (int t = 0; t < MB; ++t) {
+            const int R = 8 * (wave * MB + t) + (lane >> 3);
+            const int c = (lane & 7) ^ ((R >> 1) & 7);
+            asrc[t] = A + (size_t)min(s_m0 + R, M - 1) * lda + c * 8;
+        }
+        const int R = TM + 8 * (wave & 3) + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        axsrc = A + (size_t)min(s_m0 + R, M - 1) * lda + c * 8;
+        blk0 += s_take;
+        cnt -= s_take;
+    };
+    // one 1-KiB LDS-DMA piece of a K-tile (compile-time index: MB A pieces, 4 B pieces, the extra block's piece)
+    auto piece = [&](auto ptag, int buf, int k0) __attribute__((always_inline)) {
+        constexpr int P = decltype(ptag)::value;
+        if constexpr (P < MB)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[P < MB ? P : 0] + k0),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (wave * MB + P) * 1024), 16, 0, 0);
+        else if constexpr (P < MB + 4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[P >= MB && P < MB + 4 ? P - MB : 0] + k0),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (TM + 32) * 128 + (wave * 4 + P - MB) * 1024), 16, 0, 0);
+        else if constexpr (P == MB + 4) {
+            if (s_extra && wave < 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(axsrc + k0),
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * STAGE + TM * 128 + wave * 1024), 16, 0, 0);
+        }
+    };
+    auto stage = [&](int buf, int k0) {
+        piece(std::integral_constant<int, 0>{}, buf, k0);
+        piece(std::integral_constant<int, 1>{}, buf, k0);
+        piece(std::integral_constant<int, 2>{}, buf, k0);
+        piece(std::integral_constant<int, 3>{}, buf, k0);
+        piece(std::integral_constant<int, 4>{}, buf, k0);
+        piece(std::integral_constant<int, 5>{}, buf, k0);
+        piece(std::integral_constant<int, 6>{}, buf, k0);
+        piece(std::integral_constant<int, 7>{}, buf, k0);
+        piece(std::integral_constant<int, 8>{}, buf, k0);
+    };
+    constexpr int PPK = (MB + 5 + 2) / 3;  // pieces issued behind each of the first three k-steps' MFMAs
+
+    setup();
+    stage(0, 0);
+    int pend = 0;          // upper bound of the epilogue stores issued after the newest staged K-tile
+    bool kt1 = false;      // the second K-tile of the current sub-tile was staged ahead of the previous epilogue
+    while (true) {
+        const int c_m0 = s_m0, c_mlim = s_mlim, c_take = s_take;
+        const bool extra = s_extra;
+        const bool more = cnt > 0;
+        const int pieces = MB + 4 + ((extra && wave < 4) ? 1 : 0);
+        f32x16 acc[MB][2], accx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accx[r] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                acc[i][0][r] = 0.0f;
+                acc[i][1][r] = 0.0f;
+            }
+        }
+        // accumulate: the old values of C.  One workgroup per CU has nothing else to run while a load is in flight, so they
+        // are requested ahead of their use: the first two half-blocks' right behind the last MFMAs, then two more behind
+        // every half-block that has left (4 registers per store; every staged accumulator half frees 16).  Rows past the
+        // sub-tile's end are clamped (masked on the store).
+        uint4 oldv[2 * MB][2], oldx[2];
+        auto fetch_old = [&](auto hbtag) __attribute__((always_inline)) {
+            constexpr int hb = decltype(hbtag)::value;
+            if constexpr (ACC && hb < 2 * MB) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int q = lane + 64 * it, lr = q >> 3, c8 = q & 7;
+                    const int row = min(c_m0 + wm * 32 * MB + hb * 16 + lr, M - 1);
+                    oldv[hb][it] = *reinterpret_cast<const uint4*>(C + (size_t)row * ldc + n0 + wn * 64 + c8 * 8);
+                }
+            } else if constexpr (ACC && hb < 2 * MB + 2) {
+                if (extra) {
+                    const int row = min(c_m0 + TM + 16 * (hb - 2 * MB) + (lane >> 2), M - 1);
+                    oldx[hb - 2 * MB] = *reinterpret_cast<const uint4*>(C + (size_t)row * ldc + n0 + wave * 32 + (lane & 3) * 8);
+                }
+            }
+        };
+        for (int t = 0; t < nkt; ++t) {
+            // K-tile t has landed: this wave's pieces by the counted wait, everyone's by the barrier, which also says that
+            // every wave is done reading the other buffer
+            if (t == 0) vmwait_upto(kt1 ? pend + pieces : pend);
+            else if (t == 1 && kt1) vmwait_upto(pend);
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            bool dma = false;
+            int dbuf = 0, dk0 = 0;
+            if (t + 1 < nkt) {
+                if (!(t == 0 && kt1)) { dma = true; dbuf = (t + 1) & 1; dk0 = (t + 1) * 64; }
+            } else if (more) {
+                setup();       // the descriptors now describe the NEXT sub-tile; its first K-tile goes to buffer 0
+                dma = true;
+            }
+            const unsigned char* sp = smem + (t & 1) * STAGE;
+            auto kstep = [&](auto kstag) __attribute__((always_inline)) {
+                constexpr int ks = decltype(kstag)::value;
+                const int ch = ((ks * 2 + fh) ^ swz) * 16;
+                bf16x8 a[MB], b[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) b[f] = *reinterpret_cast<const bf16x8*>(sp + fb_off + f * 32 * 128 + ch);
+#pragma unroll
+                for (int f = 0; f < MB; ++f) a[f] = *reinterpret_cast<const bf16x8*>(sp + fa_off + f * 32 * 128 + ch);
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                if (extra) {
+                    const bf16x8 ax = *reinterpret_cast<const bf16x8*>(sp + fax_off + ch);
+                    const bf16x8 bx = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax, bx, accx, 0, 0, 0);
+                }
+                if constexpr (ks < 3) {
+                    if (dma) {
+                        piece(std::integral_constant<int, ks * PPK + 0>{}, dbuf, dk0);
+                        if constexpr (PPK > 1) piece(std::integral_constant<int, ks * PPK + 1>{}, dbuf, dk0);
+                        if constexpr (PPK > 2) piece(std::integral_constant<int, ks * PPK + 2>{}, dbuf, dk0);
+                    }
+                }
+            };
+            kstep(std::integral_constant<int, 0>{});
+            kstep(std::integral_constant<int, 1>{});
+            kstep(std::integral_constant<int, 2>{});
+            kstep(std::integral_constant<int, 3>{});
+        }
+        kt1 = false;
+        if (PRE1 && more) {
+            __builtin_amdgcn_s_barrier();   // every wave is done with buffer 1
+            stage(1, 64);
+            kt1 = true;
+        }
+        fetch_old(std::integral_constant<int, 0>{});
+        fetch_old(std::integral_constant<int, 1>{});
+        if (!PRE1) __syncthreads();         // the epilogue stages through buffer 1
+        pend = 0;
+        {
+            float* st = reinterpret_cast<float*>(smem + EPI_OFF + wave * 4352);
+            constexpr int SLD = 68;
+            const bool exact = c_take >= 2 * MB && c_mlim == c_m0 + c_take * 32;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            auto pack_store = [&](const float* v, const float* bb, const uint4& old, int row, int col) __attribute__((always_inline)) {
+                bf16_t* dst = C + (size_t)row * ldc + col;
+                float w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = v[u] + bb[u];
+                if constexpr (ACC) {
+                    w[0] += __uint_as_float(old.x << 16); w[1] += __uint_as_float(old.x & 0xffff0000u);
+                    w[2] += __uint_as_float(old.y << 16); w[3] += __uint_as_float(old.y & 0xffff0000u);
+                    w[4] += __uint_as_float(old.z << 16); w[5] += __uint_as_float(old.z & 0xffff0000u);
+                    w[6] += __uint_as_float(old.w << 16); w[7] += __uint_as_float(old.w & 0xffff0000u);
+                }
+                u32x4 o;
+                o.x = (unsigned)f2bf(w[0]) | ((unsigned)f2bf(w[1]) << 16);
+                o.y = (unsigned)f2bf(w[2]) | ((unsigned)f2bf(w[3]) << 16);
+                o.z = (unsigned)f2bf(w[4]) | ((unsigned)f2bf(w[5]) << 16);
+                o.w = (unsigned)f2bf(w[6]) | ((unsigned)f2bf(w[7]) << 16);
+                // s_nop 1: the hardware reads a 16-byte store's data registers a state after issue; hipcc pads nothing inside an asm string
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(o) : "memory");
+            };
+            auto emit64 = [&](int row0, bool masked, const uint4 (&old)[2]) __attribute__((always_inline)) {  // 16 rows x 64 columns: 2 stores per lane
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int q = lane + 64 * it, lr = q >> 3, c8 = q & 7;
+                    const float4 lo = *reinterpret_cast<const float4*>(st + lr * SLD + c8 * 8);
+                    const float4 hi = *reinterpret_cast<const float4*>(st + lr * SLD + c8 * 8 + 4);
+                    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    if (!masked || row0 + lr < c_mlim) pack_store(v, bv, old[it], row0 + lr, n0 + wn * 64 + c8 * 8);
+                }
+            };
+            auto emit32 = [&](int row0, bool masked, const uint4& old) __attribute__((always_inline)) {  // 16 rows x 32 columns: 1 store per lane
+                const int lr = lane >> 2, c8 = lane & 3;
+                const float4 lo = *reinterpret_cast<const float4*>(st + lr * SLD + c8 * 8);
+                const float4 hi = *reinterpret_cast<const float4*>(st + lr * SLD + c8 * 8 + 4);
+                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (!masked || row0 + lr < c_mlim) pack_store(v, bvx, old, row0 + lr, n0 + wave * 32 + c8 * 8);
+            };
+            auto half = [&](auto hbtag, auto masked_tag) __attribute__((always_inline)) {
+                constexpr int hb = decltype(hbtag)::value;
+                constexpr bool MASKED = decltype(masked_tag)::value;
+                if constexpr (hb < 2 * MB) {
+                    constexpr int i = hb >> 1, h = hb & 1;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 8; ++r)
+                            st[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + j * 32 + (lane & 31)] = acc[i][j][8 * h + r];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    emit64(c_m0 + wm * 32 * MB + hb * 16, MASKED, oldv[hb]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                } else if constexpr (hb < 2 * MB + 2) {
+                    if (extra) {
+                        constexpr int h = hb - 2 * MB;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + (lane & 31)] = accx[8 * h + r];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        emit32(c_m0 + TM + 16 * h, MASKED, oldx[h]);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    }
+                }
+                fetch_old(std::integral_constant<int, 2 * hb + 2>{});
+                fetch_old(std::integral_constant<int, 2 * hb + 3>{});
+            };
+            auto run = [&](auto mt) __attribute__((always_inline)) {
+                half(std::integral_constant<int, 0>{}, mt);
+                half(std::integral_constant<int, 1>{}, mt);
+                half(std::integral_constant<int, 2>{}, mt);
+                half(std::integral_constant<int, 3>{}, mt);
+                half(std::integral_constant<int, 4>{}, mt);
+                half(std::integral_constant<int, 5>{}, mt);
+                half(std::integral_constant<int, 6>{}, mt);
+                half(std::integral_constant<int, 7>{}, mt);
+                half(std::integral_constant<int, 8>{}, mt);
+                half(std::integral_constant<int, 9>{}, mt);
+            };
+            if (exact) {
+                // every lane issues exactly 4 MB (+2) stores: the count the next waits leave outstanding.  (With
+                // accumulate the old values' loads are younger than the staged DMA too, but they have returned by the
+                // time their stores issue, so the bound holds.)
+                run(std::false_type{});
+                pend = 4 * MB + (extra ? 2 : 0);
+            } else {
+                run(std::true_type{});
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        if (!more) break;
+    }
+}
+
+// the uneven shares of the strip kernel: `groups` row groups of base (+1 for the first rem) 32-row blocks; picks the
+// wave-row height MB whose sub-tiles (2 MB or 2 MB + 1 blocks) cover base and base + 1 without padding
+inline bool strip_plan(int M, int N, int K, int& MB, int& nstrips, int& groups, int& base, int& rem) {
+    static const int enabled = getenv("SPV_GEMM_STRIP") ? atoi(getenv("SPV_GEMM_STRIP")) : 1;
+    if (!enabled || N % 256 != 0 || N > 1024 || K % 128 != 0 || K < 128 || M < 8192) return false;
+    nstrips = N / 256;
+    const int nblk = cdiv(M, 32);
+    groups = 256 / nstrips;
+    if (groups > nblk) groups = nblk;
+    base = nblk / groups;
+    rem = nblk % groups;
+    auto padded = [&](int mb, int c) {  // MFMA block slots a run of c blocks occupies
+        int slots = 0;
+        while (c > 0) {
+            const int take = (c % (2 * mb) != 0 && c >= 2 * mb + 1) ? 2 * mb + 1 : std::min(2 * mb, c);
+            slots += take >= 2 * mb ? take : 2 * mb;
+            c -= take;
+        }
+        return slots;
+    };
+    int best = 0, best_slots = 1 << 30;
+    const int worst = base + (rem ? 1 : 0);
+    for (int mb = 4; mb >= 2; --mb) {
+        const int s = padded(mb, worst);
+        if (s < best_slots) { best_slots = s; best = mb; }
+    }
+    if (best == 0 || best_slots * 100 > worst * 115) return false;  // more than 15 % padding: the 128 x 128 kernels do better
+    MB = best;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // TN contraction: C[M,N] = sum_k A[k][m] * B[k][n]  with A [K, lda>=M] and B [K, ldb>=N] row-major (bf16).
 // This is the weight gradient dW = dh^T . x taken straight from the row-major activations: no transposed copies.
 // Tiles are staged in LDS exactly as they lie in memory ([k][m] rows of 256 B + 64 B pad, coalesced 16-byte loads);
@@ -545,6 +887,30 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
     }
     float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
     dim3 grid(tiles_m * tiles_n * splits);
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+        int mb, nstrips, groups, base, rem;
+        if (splits == 1 && rg == 0 && bias2d == nullptr && bc == nullptr && ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+            (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 3) == 0) && strip_plan(M, N, K, mb, nstrips, groups, base, rem)) {
+            const int nwg = groups * nstrips;
+#define SPV_STRIP(MBV, ACCV)                                                                                                \
+    hipLaunchKernelGGL((gemm_nt_strip_kernel<MBV, ACCV>), dim3(nwg), dim3(512), 0, st, static_cast<const bf16_t*>(A),       \
+                       static_cast<const bf16_t*>(B), bias, static_cast<bf16_t*>(C), M, K, lda, ldb, ldc, nstrips, base, rem, nwg)
+            static const int acc_mb = getenv("SPV_STRIP_ACC_MB") ? atoi(getenv("SPV_STRIP_ACC_MB")) : 0;  // tuning aid
+            if (accumulate && acc_mb >= 2 && acc_mb <= 4) mb = acc_mb;
+            if (accumulate) {
+                if (mb == 4) SPV_STRIP(4, true);
+                else if (mb == 3) SPV_STRIP(3, true);
+                else SPV_STRIP(2, true);
+            } else {
+                if (mb == 4) SPV_STRIP(4, false);
+                else if (mb == 3) SPV_STRIP(3, false);
+                else SPV_STRIP(2, false);
+            }
+#undef SPV_STRIP
+            SPV_LAUNCH_CHECK("spv_gemm_nt(strip)");
+            return 0;
+        }
+    }
     if constexpr (sizeof(T) == 2) {
         // direct-to-LDS double-buffered kernel for long reductions (measured: 896 vs 795 TFLOP/s at 4096^3, 755 vs 700 on
         // the 512 x 8192 x 33280 weight gradient); the skinny K <= 1024 layer GEMMs are faster on the register-staged
