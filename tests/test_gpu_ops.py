@@ -69,7 +69,7 @@ def test_gemm_nt(ops, dtype, M, N, K, splits):
 
 
 @pytest.mark.parametrize("M,N,K", [(33280, 768, 512), (33280, 512, 768), (33270, 256, 128), (20000, 512, 384), (33280, 1024, 256),
-                                   (94203, 512, 128)])
+                                   (94203, 512, 128), (33280, 1536, 512), (16640, 2048, 128)])
 def test_gemm_nt_strip_kernel(ops, M, N, K):
     """The one-workgroup-per-CU strip kernel (bf16 out, N % 256 == 0, K % 128 == 0, M >= 8192) against the 128 x 128 kernel of
     the same library (fp32 out never takes the strip path): same MFMA order along K, so the bf16 results must be the

@@ -312,21 +312,83 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
                 acc[i][1][r] = 0.0f;
             }
         }
+        auto kloop6 = [&](auto extra_tag) __attribute__((always_inline)) {
+            constexpr bool EXTRA = decltype(extra_tag)::value;
+            constexpr int PPK4 = (MB + 4 + 2) / 3;
+            for (int t = 0; t < nkt; ++t) {
+                if (t == 0) vmwait_rt(kt1 ? pend + pieces : pend);
+                else if (t == 1 && kt1) vmwait_rt(pend + pieces);
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                int dbuf = 0, dk0 = 0;
+                if (t + 1 < nkt) { dbuf = (t + 1) & 1; dk0 = (t + 1) * 64; }
+                else if (more) setup();   // (no next sub-tile: a dummy re-stage of this one's first K-tile into the idle buffer 0)
+                piece(std::integral_constant<int, MB + 4>{}, dbuf, dk0);
+                const unsigned char* sp = smem + (t & 1) * STAGE;
+                bf16x8 hb0, hb1, ha0;
+                auto head = [&](auto kstag, bf16x8& x0, bf16x8& x1, bf16x8& y0) __attribute__((always_inline)) {
+                    constexpr int ks = decltype(kstag)::value;
+                    const int ch = ((ks * 2 + fh) ^ swz) * 16;
+                    x0 = *reinterpret_cast<const bf16x8*>(sp + fb_off + ch);
+                    x1 = *reinterpret_cast<const bf16x8*>(sp + fb_off + 32 * 128 + ch);
+                    y0 = *reinterpret_cast<const bf16x8*>(sp + fa_off + ch);
+                };
+                auto kstep6 = [&](auto kstag) __attribute__((always_inline)) {
+                    constexpr int ks = decltype(kstag)::value;
+                    const int ch = ((ks * 2 + fh) ^ swz) * 16;
+                    bf16x8 ar[MB], ax, bx;
+#pragma unroll
+                    for (int f = 1; f < MB; ++f) ar[f] = *reinterpret_cast<const bf16x8*>(sp + fa_off + f * 32 * 128 + ch);
+                    if constexpr (EXTRA) {
+                        ax = *reinterpret_cast<const bf16x8*>(sp + fax_off + ch);
+                        bx = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha0, hb0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha0, hb1, acc[0][1], 0, 0, 0);
+                    bf16x8 nb0, nb1, na0;
+                    if constexpr (ks < 3) head(std::integral_constant<int, ks + 1>{}, nb0, nb1, na0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 1; i < MB; ++i) {
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], hb0, acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], hb1, acc[i][1], 0, 0, 0);
+                    }
+                    if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax, bx, accx, 0, 0, 0);
+                    if constexpr (ks < 3) {
+                        if constexpr (ks * PPK4 + 0 < MB + 4) piece(std::integral_constant<int, ks * PPK4 + 0>{}, dbuf, dk0);
+                        if constexpr (ks * PPK4 + 1 < MB + 4 && PPK4 > 1) piece(std::integral_constant<int, ks * PPK4 + 1>{}, dbuf, dk0);
+                        if constexpr (ks * PPK4 + 2 < MB + 4 && PPK4 > 2) piece(std::integral_constant<int, ks * PPK4 + 2>{}, dbuf, dk0);
+                        hb0 = nb0; hb1 = nb1; ha0 = na0;
+                    }
+                };
+                head(std::integral_constant<int, 0>{}, hb0, hb1, ha0);
+                kstep6(std::integral_constant<int, 0>{});
+                kstep6(std::integral_constant<int, 1>{});
+                kstep6(std::integral_constant<int, 2>{});
+                kstep6(std::integral_constant<int, 3>{});
+            }
+        };
+        if constexpr (IL == 6) {
+            if (extra) kloop6(std::true_type{});
+            else kloop6(std::false_type{});
+        } else
         for (int t = 0; t < nkt; ++t) {
             if (t == 0) vmwait_rt(kt1 ? pend + pieces : pend);
-            else if (t == 1 && kt1) vmwait_rt(pend);
+            else if (t == 1 && kt1) vmwait_rt(IL == 4 ? pend + pieces : pend);
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             bool dma = false;
             int dbuf = 0, dk0 = 0;
             if (t + 1 < nkt) {
-                if (!(t == 0 && kt1)) { dma = true; dbuf = (t + 1) & 1; dk0 = (t + 1) * 64; }
+                if (IL == 4 || !(t == 0 && kt1)) { dma = true; dbuf = (t + 1) & 1; dk0 = (t + 1) * 64; }
             } else if (more) {
                 setup();       // the descriptors now describe the NEXT sub-tile
                 dma = true;
             }
             if (!IL && dma) stage(dbuf, dk0);
             if (IL == 3) dma = dma && true;
+            if (IL == 4) piece(std::integral_constant<int, MB + 4>{}, dbuf, dk0);  // (last K-tile of the workgroup: a dummy re-stage into the idle buffer 0)
             const unsigned char* sp = smem + (t & 1) * STAGE;
             auto kstep = [&](auto kstag) {
                 constexpr int ks = decltype(kstag)::value;
@@ -336,6 +398,11 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
                 for (int f = 0; f < 2; ++f) b[f] = *reinterpret_cast<const bf16x8*>(sp + fb_off + f * 32 * 128 + ch);
 #pragma unroll
                 for (int f = 0; f < MB; ++f) a[f] = *reinterpret_cast<const bf16x8*>(sp + fa_off + f * 32 * 128 + ch);
+                bf16x8 ax4, bx4;
+                if constexpr (IL == 4) {
+                    ax4 = *reinterpret_cast<const bf16x8*>(sp + fax_off + ch);
+                    bx4 = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
+                }
                 if constexpr (PR == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
@@ -343,6 +410,17 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
                 if constexpr (PR == 2) __builtin_amdgcn_s_setprio(0);
+                if constexpr (IL == 4) {
+                    constexpr int PPK4 = (MB + 4 + 2) / 3;
+                    asm volatile("" ::"v"(ax4), "v"(bx4));  // keeps the two reads up with the others (hipcc sinks them into the branch)
+                    if (extra) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax4, bx4, accx, 0, 0, 0);
+                    if constexpr (ks < 3) {
+                        if constexpr (ks * PPK4 + 0 < MB + 4) piece(std::integral_constant<int, ks * PPK4 + 0>{}, dbuf, dk0);
+                        if constexpr (ks * PPK4 + 1 < MB + 4 && PPK4 > 1) piece(std::integral_constant<int, ks * PPK4 + 1>{}, dbuf, dk0);
+                        if constexpr (ks * PPK4 + 2 < MB + 4 && PPK4 > 2) piece(std::integral_constant<int, ks * PPK4 + 2>{}, dbuf, dk0);
+                    }
+                    return;
+                }
                 if (extra) {
                     const bf16x8 ax = *reinterpret_cast<const bf16x8*>(sp + fax_off + ch);
                     const bf16x8 bx = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
@@ -357,7 +435,54 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
                     if constexpr (IL == 2) __builtin_amdgcn_sched_barrier(0);
                 }
             };
-            if constexpr (IL != 3) {
+            if constexpr (IL == 5) {
+                // head fragments (both B blocks + the first A block) of k-step s+1 are read behind the first two MFMAs of
+                // k-step s, so a k-step starts issuing MFMAs at once and its remaining A reads land under them
+                bf16x8 hb0, hb1, ha0;
+                auto head = [&](auto kstag, bf16x8& x0, bf16x8& x1, bf16x8& y0) __attribute__((always_inline)) {
+                    constexpr int ks = decltype(kstag)::value;
+                    const int ch = ((ks * 2 + fh) ^ swz) * 16;
+                    x0 = *reinterpret_cast<const bf16x8*>(sp + fb_off + ch);
+                    x1 = *reinterpret_cast<const bf16x8*>(sp + fb_off + 32 * 128 + ch);
+                    y0 = *reinterpret_cast<const bf16x8*>(sp + fa_off + ch);
+                };
+                auto kstep5 = [&](auto kstag) __attribute__((always_inline)) {
+                    constexpr int ks = decltype(kstag)::value;
+                    const int ch = ((ks * 2 + fh) ^ swz) * 16;
+                    bf16x8 ar[MB];
+#pragma unroll
+                    for (int f = 1; f < MB; ++f) ar[f] = *reinterpret_cast<const bf16x8*>(sp + fa_off + f * 32 * 128 + ch);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha0, hb0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha0, hb1, acc[0][1], 0, 0, 0);
+                    bf16x8 nb0, nb1, na0;
+                    if constexpr (ks < 3) head(std::integral_constant<int, ks + 1>{}, nb0, nb1, na0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 1; i < MB; ++i) {
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], hb0, acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], hb1, acc[i][1], 0, 0, 0);
+                    }
+                    if (extra) {
+                        const bf16x8 ax = *reinterpret_cast<const bf16x8*>(sp + fax_off + ch);
+                        const bf16x8 bx = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
+                        accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax, bx, accx, 0, 0, 0);
+                    }
+                    if constexpr (ks < 3) {
+                        if (dma) {
+                            piece(std::integral_constant<int, ks * PPK + 0>{}, dbuf, dk0);
+                            if constexpr (PPK > 1) piece(std::integral_constant<int, ks * PPK + 1>{}, dbuf, dk0);
+                            if constexpr (PPK > 2) piece(std::integral_constant<int, ks * PPK + 2>{}, dbuf, dk0);
+                        }
+                        hb0 = nb0; hb1 = nb1; ha0 = na0;
+                    }
+                };
+                head(std::integral_constant<int, 0>{}, hb0, hb1, ha0);
+                kstep5(std::integral_constant<int, 0>{});
+                kstep5(std::integral_constant<int, 1>{});
+                kstep5(std::integral_constant<int, 2>{});
+                kstep5(std::integral_constant<int, 3>{});
+            } else if constexpr (IL != 3) {
                 kstep(std::integral_constant<int, 0>{});
                 kstep(std::integral_constant<int, 1>{});
                 kstep(std::integral_constant<int, 2>{});
@@ -514,6 +639,7 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
         }
         if (!more) break;
     }
+    if (IL == 4 || IL == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy re-stage must not outlive the workgroup's LDS
 }
 
 template <int MB, int ABL, int IL = 0, int ST = 0, int PR = 0>
@@ -596,19 +722,19 @@ int main(int argc, char** argv) {
     compare("big2 MB=" #MB " IL=" #IL " ST=" #ST " PR=" #PR);
 #define TIMEV(MB, ABL, IL, ST, PR) time_us([&] { launch_big2<MB, ABL, IL, ST, PR>(A, B, bias, C, M, N, K, nullptr); }, 20)
     if (N == 768) {
-        CHECKV(3, 1, 2, 0) CHECKV(3, 1, 2, 1) CHECKV(3, 1, 2, 2) CHECKV(3, 1, 2, 3)
+        CHECKV(3, 1, 2, 0) CHECKV(3, 5, 2, 0) CHECKV(3, 6, 2, 0)
         for (int r = 0; r < rounds; ++r) {
             const float t0 = time_us([&] { spv_gemm_nt(A, B, bias, Cref, M, N, K, K, K, N, SPV_BF16, SPV_BF16, 0, 1, nullptr, nullptr); }, 20);
-            const float a = TIMEV(3, 0, 1, 2, 0), b = TIMEV(3, 0, 1, 2, 1), c = TIMEV(3, 0, 1, 2, 2), c3 = TIMEV(3, 0, 1, 2, 3), d = TIMEV(3, 1, 1, 2, 0), e = TIMEV(3, 1, 1, 2, 1), f = TIMEV(3, 1, 1, 2, 2);
-            printf("round %d: shipped %6.2f | MB=3 IL1+sc1 prio: none %6.2f  static %6.2f  pair %6.2f  static-rev %6.2f | no store: none %6.2f static %6.2f pair %6.2f\n", r, t0, a, b, c, c3, d, e, f);
+            const float a = TIMEV(3, 0, 1, 2, 0), b = TIMEV(3, 0, 5, 2, 0), c = TIMEV(3, 0, 6, 2, 0), d = TIMEV(3, 1, 1, 2, 0), e = TIMEV(3, 1, 5, 2, 0), f = TIMEV(3, 1, 6, 2, 0);
+            printf("round %d: product %6.2f | MB=3 IL1 %6.2f  IL5 %6.2f | IL6 %6.2f | MB=3 no store: IL1 %6.2f IL5 %6.2f  IL6 %6.2f\n", r, t0, a, b, c, d, e, f);
             fflush(stdout);
         }
     } else {
-        CHECKV(4, 1, 2, 0) CHECKV(4, 1, 2, 1) CHECKV(4, 1, 2, 2) CHECKV(4, 1, 2, 3)
+        CHECKV(4, 1, 2, 0) CHECKV(4, 5, 2, 0) CHECKV(4, 6, 2, 0)
         for (int r = 0; r < rounds; ++r) {
             const float t0 = time_us([&] { spv_gemm_nt(A, B, bias, Cref, M, N, K, K, K, N, SPV_BF16, SPV_BF16, 0, 1, nullptr, nullptr); }, 20);
-            const float a = TIMEV(4, 0, 1, 2, 0), b = TIMEV(4, 0, 1, 2, 1), c = TIMEV(4, 0, 1, 2, 2), c3 = TIMEV(4, 0, 1, 2, 3), d = TIMEV(4, 1, 1, 2, 0), e = TIMEV(4, 1, 1, 2, 1), f = TIMEV(4, 1, 1, 2, 2);
-            printf("round %d: shipped %6.2f | MB=4 IL1+sc1 prio: none %6.2f  static %6.2f  pair %6.2f  static-rev %6.2f | no store: none %6.2f static %6.2f pair %6.2f\n", r, t0, a, b, c, c3, d, e, f);
+            const float a = TIMEV(4, 0, 1, 2, 0), b = TIMEV(4, 0, 5, 2, 0), c = TIMEV(4, 0, 6, 2, 0), d = TIMEV(4, 1, 1, 2, 0), e = TIMEV(4, 1, 5, 2, 0), f = TIMEV(4, 1, 6, 2, 0);
+            printf("round %d: product %6.2f | MB=4 IL1 %6.2f  IL5 %6.2f | IL6 %6.2f | MB=4 no store: IL1 %6.2f IL5 %6.2f  IL6 %6.2f\n", r, t0, a, b, c, d, e, f);
             fflush(stdout);
         }
     }

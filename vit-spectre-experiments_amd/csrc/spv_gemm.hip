@@ -456,7 +456,8 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
     constexpr int EPI_OFF = PRE1 ? 2 * STAGE : STAGE; // MB = 4: the epilogue stages through K-tile buffer 1
     constexpr int BIAS_OFF = PRE1 ? 2 * STAGE + EPI : 2 * STAGE;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BIAS_OFF + 1024];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases and wave offsets stay in SGPRs
     const int wm = wave >> 2, wn = wave & 3;
     // the strips of one row group sit on one XCD and run together: its A rows are fetched into that L2 once
     const int id = xcd_remap(blockIdx.x, nwg);
@@ -552,9 +553,11 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
             }
         }
         // accumulate: the old values of C.  One workgroup per CU has nothing else to run while a load is in flight, so they
-        // are requested ahead of their use: the first two half-blocks' right behind the last MFMAs, then two more behind
-        // every half-block that has left (4 registers per store; every staged accumulator half frees 16).  Rows past the
-        // sub-tile's end are clamped (masked on the store).
+        // are requested two half-blocks ahead of their use (4 registers per store).  Rows past the sub-tile's end are
+        // clamped (masked on the store).  (Touch loads that pull the lines towards the L2 during the K loop, or a deeper
+        // window, measured the same or worse: the read-modify-write costs its bytes -- 51 MB more per launch in a phase in
+        // which every CU is storing -- not its latency.)
+        int e_m0 = 0;  // the sub-tile's first row again, set behind the K loop
         uint4 oldv[2 * MB][2], oldx[2];
         auto fetch_old = [&](auto hbtag) __attribute__((always_inline)) {
             constexpr int hb = decltype(hbtag)::value;
@@ -562,12 +565,12 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
 #pragma unroll
                 for (int it = 0; it < 2; ++it) {
                     const int q = lane + 64 * it, lr = q >> 3, c8 = q & 7;
-                    const int row = min(c_m0 + wm * 32 * MB + hb * 16 + lr, M - 1);
+                    const int row = min(e_m0 + wm * 32 * MB + hb * 16 + lr, M - 1);
                     oldv[hb][it] = *reinterpret_cast<const uint4*>(C + (size_t)row * ldc + n0 + wn * 64 + c8 * 8);
                 }
             } else if constexpr (ACC && hb < 2 * MB + 2) {
                 if (extra) {
-                    const int row = min(c_m0 + TM + 16 * (hb - 2 * MB) + (lane >> 2), M - 1);
+                    const int row = min(e_m0 + TM + 16 * (hb - 2 * MB) + (lane >> 2), M - 1);
                     oldx[hb - 2 * MB] = *reinterpret_cast<const uint4*>(C + (size_t)row * ldc + n0 + wave * 32 + (lane & 3) * 8);
                 }
             }
@@ -619,6 +622,8 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
             kstep(std::integral_constant<int, 2>{});
             kstep(std::integral_constant<int, 3>{});
         }
+        e_m0 = c_m0;                    // opaque copy made behind the K loop: hipcc otherwise computes the epilogue's row
+        asm volatile("" : "+s"(e_m0));  // addresses before the loop and carries them through it in registers (spills)
         kt1 = false;
         if (PRE1 && more) {
             __builtin_amdgcn_s_barrier();   // every wave is done with buffer 1
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
                         for (int r = 0; r < 8; ++r)
                             st[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + j * 32 + (lane & 31)] = acc[i][j][8 * h + r];
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    emit64(c_m0 + wm * 32 * MB + hb * 16, MASKED, oldv[hb]);
+                    emit64(e_m0 + wm * 32 * MB + hb * 16, MASKED, oldv[hb]);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 } else if constexpr (hb < 2 * MB + 2) {
                     if (extra) {
@@ -689,12 +694,11 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
 #pragma unroll
                         for (int r = 0; r < 8; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + (lane & 31)] = accx[8 * h + r];
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        emit32(c_m0 + TM + 16 * h, MASKED, oldx[h]);
+                        emit32(e_m0 + TM + 16 * h, MASKED, oldx[h]);
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     }
                 }
-                fetch_old(std::integral_constant<int, 2 * hb + 2>{});
-                fetch_old(std::integral_constant<int, 2 * hb + 3>{});
+                fetch_old(std::integral_constant<int, hb + 2>{});
             };
             auto run = [&](auto mt) __attribute__((always_inline)) {
                 half(std::integral_constant<int, 0>{}, mt);
@@ -727,7 +731,7 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
 // wave-row height MB whose sub-tiles (2 MB or 2 MB + 1 blocks) cover base and base + 1 without padding
 inline bool strip_plan(int M, int N, int K, int& MB, int& nstrips, int& groups, int& base, int& rem) {
     static const int enabled = getenv("SPV_GEMM_STRIP") ? atoi(getenv("SPV_GEMM_STRIP")) : 1;
-    if (!enabled || N % 256 != 0 || N > 1024 || K % 128 != 0 || K < 128 || M < 8192) return false;
+    if (!enabled || N % 256 != 0 || N > 2048 || K % 128 != 0 || K < 128 || M < 8192) return false;
     nstrips = N / 256;
     const int nblk = cdiv(M, 32);
     groups = 256 / nstrips;
@@ -775,7 +779,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <typename TO>
+template <typename TO, int DEPTH>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                       TO* __restrict__ C, float* __restrict__ ws, int M, int N, int K, int lda,
                                                       int ldb, int ldc, int k_per_split, int accumulate, int tiles_n,
@@ -799,8 +803,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     // staging map: TBK k rows x 16 chunks of 16 B per operand -> TBK / 16 chunks per thread per operand
     const int srow = tid >> 4, sch = tid & 15;  // rows srow + 16 i
     const bool a_ok = (m0 + sch * 8) < M, b_ok = (n0 + sch * 8) < N;  // M, N multiples of 8: a chunk is all in or all out
-    uint4 ra[TBK / 16], rb[TBK / 16];
-    auto load_tile = [&](int k0) {
+    // Three register sets: the loads of K-tiles t+1 .. t+3 are in flight while tile t is multiplied.  With the weight
+    // gradient's 288 workgroups (~1 per CU, one wave per SIMD) a K-tile is 16 MFMAs = 0.27 us of work per wave, far less
+    // than an HBM round trip: with one tile in flight the kernel ran at one K-tile per load latency (43 tiles x ~0.95 us).
+    typedef uint4 RegTile[TBK / 16];
+    RegTile ra0, rb0, ra1, rb1, ra2, rb2;
+    auto load_tile = [&](int k0, RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TBK / 16; ++i) {
             const int k = k0 + srow + 16 * i;
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
             rb[i] = (kin && b_ok) ? *reinterpret_cast<const uint4*>(B + (size_t)k * ldb + n0 + sch * 8) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](const RegTile& ra, const RegTile& rb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TBK / 16; ++i) {
             *reinterpret_cast<uint4*>(sA + (srow + 16 * i) * TROWB + sch * 16) = ra[i];
@@ -831,12 +839,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     const int frag_off = (8 * (g >> 1) + q) * TROWB + (16 * (g & 1) + 4 * pp) * 2;
     const unsigned char* fa0 = sA + frag_off + (wm * 64) * 2;
     const unsigned char* fb0 = sB + frag_off + (wn * 64) * 2;
-
-    load_tile(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += TBK) {
-        store_tile();
-        __syncthreads();
-        if (k0 + TBK < kend) load_tile(k0 + TBK);
+    auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < TBK / 16; ++ks) {
             bf16x8 a[2], b[2];
@@ -851,7 +854,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+    };
+    // one K-tile: its registers go to LDS, the set is refilled with the tile three ahead, then the MFMAs
+    auto step = [&](int k0, RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
+        store_tile(ra, rb);
         __syncthreads();
+        if (k0 + DEPTH * TBK < kend) load_tile(k0 + DEPTH * TBK, ra, rb);
+        multiply();
+        __syncthreads();
+    };
+
+    load_tile(kbeg, ra0, rb0);
+    if constexpr (DEPTH == 3) {
+        if (kbeg + TBK < kend) load_tile(kbeg + TBK, ra1, rb1);
+        if (kbeg + 2 * TBK < kend) load_tile(kbeg + 2 * TBK, ra2, rb2);
+        for (int k0 = kbeg; k0 < kend; k0 += 3 * TBK) {
+            step(k0, ra0, rb0);
+            if (k0 + TBK < kend) step(k0 + TBK, ra1, rb1);
+            if (k0 + 2 * TBK < kend) step(k0 + 2 * TBK, ra2, rb2);
+        }
+    } else {
+        for (int k0 = kbeg; k0 < kend; k0 += TBK) step(k0, ra0, rb0);
     }
     store_acc_tile<TO>(acc, smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr);
 }
@@ -1018,12 +1041,16 @@ extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, 
     }
     float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
     dim3 grid(tiles_m * tiles_n * splits);
-    if (out_dtype == SPV_BF16)
-        hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, ws, M, N,
-                           K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n, splits);
-    else
-        hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (float*)C, ws, M, N, K,
-                           lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n, splits);
+    static const int depth = getenv("SPV_TN_DEPTH") ? atoi(getenv("SPV_TN_DEPTH")) : 3;  // tuning aid: 1 = one K-tile in flight
+#define SPV_TN(TOV, DV)                                                                                                     \
+    hipLaunchKernelGGL((gemm_tn_kernel<TOV, DV>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (TOV*)C, ws, M, N, K, \
+                       lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n, splits)
+    if (out_dtype == SPV_BF16) {
+        if (depth == 1) SPV_TN(bf16_t, 1); else SPV_TN(bf16_t, 3);
+    } else {
+        if (depth == 1) SPV_TN(float, 1); else SPV_TN(float, 3);
+    }
+#undef SPV_TN
     SPV_LAUNCH_CHECK("spv_gemm_tn");
     if (splits > 1) {
         int blocks = (int)std::min<int64_t>(((int64_t)M * N + 255) / 256, 2048);
