@@ -95,6 +95,16 @@ int spv_spectre_tail_bwd(const void* dout, const void* h, const float* mean, con
                          float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype,
                          int dout_dtype, float p_drop, uint64_t seed, const void* dx_add, void* stream);
 int64_t spv_rowop_partial_floats(int n);
+/* spv_spectre_tail_bwd for the 512 -> 768 layer (linear1 of the encoder layer, layers.py:85-101 under spectre.py:70-73) that ALSO
+ * takes the skip gradient of the layer above (linear3, 768 -> 512) at its source: dout_eff = dout + AdaptiveAvgPool1d^T(mask_up * up_src),
+ * up_src [rows, 512] = the gradient that entered linear3's tail (`ds` of spv_spectre_tail_ln_bwd), up_p_drop / up_seed = linear3's
+ * dropout.  linear3's backward is then called with dx_pool = NULL and its data-gradient GEMM stores instead of accumulating.
+ * spv_tail_up_supported: 1 for (n, k_in) = (768, 512). */
+int spv_tail_up_supported(int n, int k_in, int dtype);
+int spv_spectre_tail_bwd_up(const void* dout, const void* h, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, void* dh, void* dx_pool, float* dgamma, float* dbeta, float* dbias, float* partials,
+                            int rows, int n, int k_in, int dtype, int dout_dtype, float p_drop, uint64_t seed, const void* dx_add,
+                            const void* up_src, float up_p_drop, uint64_t up_seed, void* stream);
 /* Second half of the encoder layer's elementwise work as ONE kernel each way:
  *   f3 = SpectreLinear3-tail(h3, f1) (as spv_spectre_tail_fwd), x2 = LayerNorm2(x1 + f3)   (spectre.py:67, 70-73)
  * spv_tail_ln_supported: shapes covered (512 outputs from 768 inputs, either dtype); otherwise compose
@@ -102,7 +112,8 @@ int64_t spv_rowop_partial_floats(int n);
  *   fwd: out = f3 (kept: the backward re-forms x1 + f3 from it), out2 = x2, mean/rstd of the tail's LayerNorm,
  *        mean2/rstd2 of LayerNorm-2; res = x1.
  *   bwd: ds = LayerNorm2-backward(dout2) (written: the residual branch needs it) is used at once as the tail's incoming
- *        gradient; dh, dx_pool, dgamma, dbeta, dbias as spv_spectre_tail_bwd; dgamma2, dbeta2 of LayerNorm-2;
+ *        gradient; dh, dx_pool (NULL: not formed, see spv_spectre_tail_bwd_up), dgamma, dbeta, dbias as spv_spectre_tail_bwd; dgamma2,
+ *        dbeta2 of LayerNorm-2;
  *        partials: spv_tail_ln_partial_floats(n) floats. */
 int spv_tail_ln_supported(int n, int k_in, int dtype);
 int64_t spv_tail_ln_partial_floats(int n);

@@ -186,6 +186,56 @@ def test_spectre_linear_golden(ops, golden_ops):
             check(pt.grad, g[f"{name}.grad.local_head.{k}"], 6e-5, name + ".grad." + k)
 
 
+@pytest.mark.parametrize("p_up", [0.0, 0.25])
+def test_tail_bwd_takes_skip_gradient_of_layer_above(ops, p_up):
+    """spv_spectre_tail_bwd_up (512 -> 768 layer): dout + pool^T(mask * up_src) formed inside the kernel must equal the old
+    composition -- the 768 -> 512 layer's backward writes dx_pool, which is added to dout -- windows, lane mapping and the
+    dropout mask of the layer above included.  bf16 storage: the composition rounds dx_pool and the sum once more."""
+    from spectre_vit import _native
+    rows, n, k = 300, 768, 512
+    g = torch.Generator(device="cpu").manual_seed(11)
+    bf = torch.bfloat16
+    rnd = lambda *shape: torch.randn(shape, generator=g).to(dev())
+    st = torch.cuda.current_stream().cuda_stream
+    # the layer above (768 -> 512): only its dx_pool = pool^T(mask * dout_up) matters here
+    dout_up, h_up = rnd(rows, k).to(bf), rnd(rows, k).to(bf)
+    mean_up, rstd_up = rnd(rows) * 0.1, rnd(rows).abs() + 0.5
+    ga_up, be_up = rnd(k), rnd(k)
+    dh_up, dxp_up = torch.empty_like(h_up), torch.empty((rows, n), dtype=bf, device=dev())
+    d3 = [torch.empty((k,), device=dev()) for _ in range(3)]
+    part = torch.empty((_native.call("spv_rowop_partial_floats", k),), device=dev())
+    seed_up = 1234567
+    _native.call("spv_spectre_tail_bwd", dout_up.data_ptr(), h_up.data_ptr(), mean_up.data_ptr(), rstd_up.data_ptr(), ga_up.data_ptr(),
+                 be_up.data_ptr(), dh_up.data_ptr(), dxp_up.data_ptr(), d3[0].data_ptr(), d3[1].data_ptr(), d3[2].data_ptr(),
+                 part.data_ptr(), rows, k, n, 1, 1, p_up, seed_up, 0, st)
+    # this layer (512 -> 768)
+    dout, h = rnd(rows, n).to(bf), rnd(rows, n).to(bf)
+    mean, rstd = rnd(rows) * 0.1, rnd(rows).abs() + 0.5
+    ga, be = rnd(n), rnd(n)
+    dx_add = rnd(rows, k).to(bf)
+
+    def run(up):
+        dh, dx = torch.empty_like(h), torch.empty((rows, k), dtype=bf, device=dev())
+        dg, db, dbi = (torch.empty((n,), device=dev()) for _ in range(3))
+        pt = torch.empty((_native.call("spv_rowop_partial_floats", n),), device=dev())
+        if up:
+            _native.call("spv_spectre_tail_bwd_up", dout.data_ptr(), h.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ga.data_ptr(),
+                         be.data_ptr(), dh.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), dbi.data_ptr(), pt.data_ptr(), rows,
+                         n, k, 1, 1, 0.0, 0, dx_add.data_ptr(), dout_up.data_ptr(), p_up, seed_up, st)
+        else:
+            dsum = (dout.float() + dxp_up.float()).to(bf)
+            _native.call("spv_spectre_tail_bwd", dsum.data_ptr(), h.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ga.data_ptr(),
+                         be.data_ptr(), dh.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), dbi.data_ptr(), pt.data_ptr(), rows,
+                         n, k, 1, 1, 0.0, 0, dx_add.data_ptr(), st)
+        torch.cuda.synchronize()
+        return [n64(v) for v in (dh, dx, dg, db, dbi)]
+
+    ref, got = run(False), run(True)
+    for name, r, v in zip(("dh", "dx", "dgamma", "dbeta", "dbias"), ref, got):
+        assert np.abs(v - r).max() <= 3e-2 * np.abs(r).max(), f"{name}: {np.abs(v - r).max()} vs max {np.abs(r).max()}"
+    assert np.abs(n64(dxp_up)).max() > 0.1  # the skip term is not trivially zero
+
+
 def test_spectre_linear_dropout(ops):
     torch.manual_seed(0)
     X = torch.randn(4096, 64, device=dev()).requires_grad_(True)

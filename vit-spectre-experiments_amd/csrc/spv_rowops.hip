@@ -683,6 +683,17 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
     }
 }
 
+// The skip gradient of the layer ABOVE, taken at its source (tail_bwd_lc<12, 8> only: the layer above is the <8, 12> one, whose
+// 12 pooled inputs per lane are exactly this kernel's 12 outputs per lane).  That layer's backward then writes no dx_pool and
+// its data-gradient GEMM stores instead of accumulating: one [rows, 768] tensor is neither written nor re-read (102 MB per
+// encoder layer), and the GEMM's epilogue loses its read-modify-write.  src = that layer's incoming gradient before its
+// dropout mask ([rows, 512]: `ds` of spv_spectre_tail_ln_bwd), p_drop / seed = that layer's dropout.
+struct TailUp {
+    const void* src;
+    float p_drop;
+    uint64_t seed;
+};
+
 // Column sums (dgamma, dbeta, dbias) live in LDS, not registers: 3*CO accumulators per lane pushed the register count
 // past the 4-waves/SIMD budget (spills).  Each wave owns [3][CO/4][64] float4 slots, lane-linear (conflict-free b128).
 template <int CO, int CI, bool FASTG, bool LN2>
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              void* __restrict__ dh, void* __restrict__ dxp, float* __restrict__ partials,
                                                              int rows, int bf, int dout_bf, float p_drop, uint64_t seed,
-                                                             const void* __restrict__ dx_add, TailLn2 ln) {
+                                                             const void* __restrict__ dx_add, TailLn2 ln, TailUp up) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int n = 64 * CO, k_in = 64 * CI, Q = CO / 4;
     constexpr int NP = LN2 ? 5 : 3;  // column-sum arrays: dgamma, dbeta, dbias (+ LayerNorm-2's dgamma, dbeta)
@@ -742,6 +753,26 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
             st_span<CO>(ln.ds, (size_t)row * n + lane * CO, bf, dv);
         } else {
             ld_span<CO>(dout, (size_t)row * n + lane * CO, dout_bf, dv);
+            if (up.src != nullptr) {
+                // + the transposed pooling of the masked gradient of the layer above (its CI outputs per lane from its CO...
+                // seen from that layer: CI of its values, pooled onto CO of its inputs = this lane's CO columns)
+                float u[CI];
+                ld_span<CI>(up.src, (size_t)row * k_in + lane * CI, bf, u);
+                if (up.p_drop > 0.0f) {
+                    const unsigned ukey = dropout_row_key(up.seed, (uint64_t)row);
+                    const float uinv = 1.0f / (1.0f - up.p_drop);
+#pragma unroll
+                    for (int c = 0; c < CI; ++c) u[c] *= dropout_scale(ukey, (unsigned)(lane * CI + c), up.p_drop, uinv);
+                }
+#pragma unroll
+                for (int j = 0; j < CO; ++j) {
+                    float a = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CI; ++c)
+                        if (j >= lc_ws(c, CI, CO) && j < lc_we(c, CI, CO)) a += u[c] * (1.0f / (float)(lc_we(c, CI, CO) - lc_ws(c, CI, CO)));
+                    dv[j] += a;
+                }
+            }
         }
         ld_span<CO>(h, (size_t)row * n + lane * CO, bf, hv);
         float s1 = 0.0f, s2 = 0.0f;
@@ -787,6 +818,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
             accw[(2 * Q + q) * 64] = v2;
         }
         st_span<CO>(dh, (size_t)row * n + lane * CO, bf, o);
+        if (dxp == nullptr) continue;  // the consumer takes the skip gradient from this layer's incoming gradient (TailUp)
         // transposed pooling, lane local: input j receives dout[c] / width(c) from every window that covers it
         float dx[CI];
 #pragma unroll
@@ -905,11 +937,11 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
     return 0;
 }
 
-extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float* mean, const float* rstd,
-                                    const float* gamma, const float* beta, void* dh, void* dx_pool, float* dgamma,
-                                    float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype,
-                                    int dout_dtype, float p_drop, uint64_t seed, const void* dx_add, void* stream) {
+static int tail_bwd_impl(const void* dout, const void* h, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                         void* dh, void* dx_pool, float* dgamma, float* dbeta, float* dbias, float* partials, int rows, int n,
+                         int k_in, int dtype, int dout_dtype, float p_drop, uint64_t seed, const void* dx_add, void* stream, TailUp up) {
     SPV_CHECK(rows > 0 && n > 0 && k_in > 0, "spv_spectre_tail_bwd: empty");
+    SPV_CHECK(up.src == nullptr || (n == 768 && k_in == 512), "spv_spectre_tail_bwd_up: only the 512 -> 768 layer takes the skip gradient of the layer above");
     SPV_CHECK(check_dtype(dtype) && check_dtype(dout_dtype), "spv_spectre_tail_bwd: bad dtype");
     RowCfg cfg;
     SPV_CHECK(pick_cfg(n, cfg), "spv_spectre_tail_bwd: unsupported row length %d", n);
@@ -921,8 +953,8 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
 #define LC_BWD(CO, CI)                                                                                                        \
         if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
             hipStream_t lst = static_cast<hipStream_t>(stream);                                                               \
-            if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{}); \
-            else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{});    \
+            if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{}, up); \
+            else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{}, up);    \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc)");                                                                     \
             hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, lst, partials, dgamma, dbeta, dbias, lwgs, 3, n); \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc fold)");                                                                \
@@ -942,6 +974,30 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
     hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, wgs, 3, n);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(fold)");
     return 0;
+}
+
+extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, void* dh, void* dx_pool, float* dgamma,
+                                    float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype,
+                                    int dout_dtype, float p_drop, uint64_t seed, const void* dx_add, void* stream) {
+    return tail_bwd_impl(dout, h, mean, rstd, gamma, beta, dh, dx_pool, dgamma, dbeta, dbias, partials, rows, n, k_in, dtype, dout_dtype,
+                         p_drop, seed, dx_add, stream, TailUp{nullptr, 0.0f, 0});
+}
+
+extern "C" int spv_tail_up_supported(int n, int k_in, int dtype) {
+    static const bool off = getenv("SPV_TAIL_NO_UP") != nullptr;
+    return (!off && n == 768 && k_in == 512 && check_dtype(dtype)) ? 1 : 0;
+}
+
+extern "C" int spv_spectre_tail_bwd_up(const void* dout, const void* h, const float* mean, const float* rstd, const float* gamma,
+                                       const float* beta, void* dh, void* dx_pool, float* dgamma, float* dbeta, float* dbias,
+                                       float* partials, int rows, int n, int k_in, int dtype, int dout_dtype, float p_drop,
+                                       uint64_t seed, const void* dx_add, const void* up_src, float up_p_drop, uint64_t up_seed,
+                                       void* stream) {
+    SPV_CHECK(up_src != nullptr && spv_tail_up_supported(n, k_in, dtype), "spv_spectre_tail_bwd_up: unsupported shape %d -> %d", k_in, n);
+    SPV_CHECK(up_p_drop >= 0.0f && up_p_drop < 1.0f, "spv_spectre_tail_bwd_up: up_p_drop=%f", up_p_drop);
+    return tail_bwd_impl(dout, h, mean, rstd, gamma, beta, dh, dx_pool, dgamma, dbeta, dbias, partials, rows, n, k_in, dtype, dout_dtype,
+                         p_drop, seed, dx_add, stream, TailUp{up_src, up_p_drop, up_seed});
 }
 
 // ---- linear3 tail + residual + LayerNorm-2 as one kernel each way (512 outputs from 768 inputs: the lane-contiguous <8, 12> kernels)
@@ -973,7 +1029,7 @@ extern "C" int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const 
                                        float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype, float p_drop,
                                        uint64_t seed, void* stream) {
     SPV_CHECK(rows > 0 && spv_tail_ln_supported(n, k_in, dtype), "spv_spectre_tail_ln_bwd: unsupported shape %d -> %d / dtype %d", k_in, n, dtype);
-    SPV_CHECK(dout2 && f3 && res && mean2 && rstd2 && gamma2 && ds && dgamma2 && dbeta2 && h && mean && rstd && gamma && beta && dh && dx_pool &&
+    SPV_CHECK(dout2 && f3 && res && mean2 && rstd2 && gamma2 && ds && dgamma2 && dbeta2 && h && mean && rstd && gamma && beta && dh &&
                   dgamma && dbeta && dbias && partials,
               "spv_spectre_tail_ln_bwd: null pointer");
     const int bfl = dtype == SPV_BF16;
@@ -981,8 +1037,8 @@ extern "C" int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const 
     const int lwgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
     const size_t lds = (size_t)RW * 5 * n * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bfl) hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, true, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln);
-    else hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, false, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln);
+    if (bfl) hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, true, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln, TailUp{nullptr, 0.0f, 0});
+    else hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, false, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln, TailUp{nullptr, 0.0f, 0});
     SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd");
     hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(5 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, lwgs, 5, n, dgamma2, dbeta2);
     SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd(fold)");

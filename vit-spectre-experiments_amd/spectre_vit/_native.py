@@ -31,6 +31,8 @@ SIGNATURES = {
     "spv_spectre_tail_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i,
                              c_i, c_f, c_u64, c_vp, c_vp],
     "spv_rowop_partial_floats": [c_i],
+    "spv_tail_up_supported": [c_i, c_i, c_i],
+    "spv_spectre_tail_bwd_up": [c_vp] * 12 + [c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_vp, c_vp, c_f, c_u64, c_vp],
     "spv_tail_ln_supported": [c_i, c_i, c_i],
     "spv_tail_ln_partial_floats": [c_i],
     "spv_spectre_tail_ln_fwd": [c_vp] * 13 + [c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],
@@ -66,7 +68,7 @@ SIGNATURES = {
 }
 _RESTYPES = {"spv_last_error": ctypes.c_char_p, "spv_rowop_partial_floats": c_i64, "spv_fnet_workspace_floats": c_i64,
              "spv_fnet_twiddle_floats": c_i64, "spv_tail_ln_partial_floats": c_i64}
-_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_tail_ln_supported"}
+_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_tail_ln_supported", "spv_tail_up_supported"}
 
 _lib = None
 

@@ -357,9 +357,10 @@ def _sl_forward(x2, weight, bias, gamma, beta, p_drop, out_fp32):
     return out, (x2, h, mean, rstd, gamma, beta, wt, sinks, rows, n, k, float(p_drop), seed)
 
 
-def _sl_backward(dout2, saved, need_dx=True, dx_add=None):
+def _sl_backward(dout2, saved, need_dx=True, dx_add=None, up=None):
     """raw SpectreLinear backward -> (dx or None, dW, dbias, dgamma, dbeta); dx_add: a gradient of the same input that is
-    folded into dx by the tail kernel (saves a separate elementwise add)"""
+    folded into dx by the tail kernel (saves a separate elementwise add); up = (src, p_drop, seed): the skip gradient of the
+    layer above, formed here from its source instead of being written by that layer and accumulated by its GEMM"""
     x2, h, mean, rstd, gamma, beta, wt, sinks, rows, n, k, p_drop, seed = saved
     dev = x2.device
     if not dout2.is_contiguous():
@@ -371,9 +372,14 @@ def _sl_backward(dout2, saved, need_dx=True, dx_add=None):
     dbeta = _grad_buf(s_be, (n,), dev)
     dbias = _grad_buf(s_b, (n,), dev)
     partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=dev)
-    _native.call("spv_spectre_tail_bwd", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
-                 _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
-                 _p(dx_add) if need_dx else 0, _stream())
+    if up is not None:
+        _native.call("spv_spectre_tail_bwd_up", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
+                     _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
+                     _p(dx_add) if need_dx else 0, _p(up[0]), float(up[1]), int(up[2]), _stream())
+    else:
+        _native.call("spv_spectre_tail_bwd", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
+                     _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
+                     _p(dx_add) if need_dx else 0, _stream())
     dw = _weight_grad(dh, x2, rows, n, k, s_w)  # side stream: overlaps the data gradient below
     if need_dx:
         _gemm(dh, wt, None, dx, rows, k, n, n, wt.shape[1], k, accumulate=1)
@@ -926,11 +932,18 @@ class FFResidualFn(torch.autograd.Function):
             dg3, dbe3, db3 = _grad_buf(s_g, (n,), dev), _grad_buf(s_be, (n,), dev), _grad_buf(s_b, (n,), dev)
             dn2w, dn2b = _grad_buf(sinks2[0], (n,), dev), _grad_buf(sinks2[1], (n,), dev)
             partials = torch.empty((_native.call("spv_tail_ln_partial_floats", n),), dtype=torch.float32, device=dev)
+            # linear3's skip gradient (its transposed pooling) is taken by linear1's tail backward from `ds` itself when the
+            # shapes allow: df1 is then a plain GEMM output (no [rows, 768] tensor written here and re-read by the GEMM)
+            defer = _native.call("spv_tail_up_supported", s1[9], s1[10], _dt(h3)) and s1[9] == k
             _native.call("spv_spectre_tail_ln_bwd", _p(d2), _p(f3), _p(x1), _p(mean2), _p(rstd2), _p(n2w), _p(ds), _p(dn2w), _p(dn2b),
-                         _p(h3), _p(mean3), _p(rstd3), _p(g3), _p(be3), _p(dh3), _p(df1), _p(dg3), _p(dbe3), _p(db3), _p(partials),
-                         rows, n, k, _dt(h3), p_drop, seed, _stream())
+                         _p(h3), _p(mean3), _p(rstd3), _p(g3), _p(be3), _p(dh3), 0 if defer else _p(df1), _p(dg3), _p(dbe3), _p(db3),
+                         _p(partials), rows, n, k, _dt(h3), p_drop, seed, _stream())
             dw3 = _weight_grad(dh3, f1, rows, n, k, s_w)
-            _gemm(dh3, wt3, None, df1, rows, k, n, n, wt3.shape[1], k, accumulate=1)
+            _gemm(dh3, wt3, None, df1, rows, k, n, n, wt3.shape[1], k, accumulate=0 if defer else 1)
+            if defer:
+                dx1, dw1, db1, dg1, dbe1 = _sl_backward(df1, s1, True, dx_add=ds, up=(ds, p_drop, seed))
+                join_side_stream()
+                return dx1.reshape(ctx.shape), dw1, db1, dg1, dbe1, dw3, db3, dg3, dbe3, dn2w, dn2b, None
         else:
             rows, n = sn[6], sn[7]
             ds, dn2w, dn2b = _addln_backward(dout.reshape(rows, n), sn)      # d(x1 + f3)
