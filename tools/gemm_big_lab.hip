@@ -369,6 +369,112 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
                 kstep6(std::integral_constant<int, 3>{});
             }
         };
+        // IL == 7: fragment reads as inline-asm ds_read_b128 with hand-counted lgkmcnt: the reads of k-step s+1 are issued
+        // before the MFMAs of k-step s and stay in flight under them (hipcc itself waits lgkmcnt(0) at every fragment use
+        // once LDS-DMA and ds_read interleave).  Two register sets of fragments.
+        auto kloop7 = [&](auto extra_tag) __attribute__((always_inline)) {
+            constexpr bool EXTRA = decltype(extra_tag)::value;
+            constexpr int NR = MB + 2 + (EXTRA ? 2 : 0);  // reads per k-step
+            const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+            unsigned adA[4], adB[4], adAX[4], adBX[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ch = ((ks * 2 + fh) ^ swz) * 16;
+                adA[ks] = lbase + fa_off + ch;
+                adB[ks] = lbase + fb_off + ch;
+                adAX[ks] = lbase + fax_off + ch;
+                adBX[ks] = lbase + fbx_off + ch;
+            }
+            struct Frag { bf16x8 a[MB], b[2], ax, bx; };
+#define LDSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+            auto issue = [&](auto kstag, unsigned boff, Frag& f) __attribute__((always_inline)) {
+                constexpr int ks = decltype(kstag)::value;
+                const unsigned pa = adA[ks] + boff, pb = adB[ks] + boff;
+                LDSR(f.b[0], pb, 0);
+                LDSR(f.b[1], pb, 4096);
+                LDSR(f.a[0], pa, 0);
+                if constexpr (MB > 1) LDSR(f.a[1], pa, 4096);
+                if constexpr (MB > 2) LDSR(f.a[2], pa, 8192);
+                if constexpr (MB > 3) LDSR(f.a[3], pa, 12288);
+                const unsigned ax_addr = adAX[ks] + boff, bx_addr = adBX[ks] + boff;
+                if constexpr (EXTRA) {
+                    LDSR(f.ax, ax_addr, 0);
+                    LDSR(f.bx, bx_addr, 0);
+                }
+            };
+            // wait until all but the N youngest LDS reads have returned; names the set's registers so that nothing that
+            // uses them is scheduled above it
+            auto settle = [&](auto ntag, Frag& f) __attribute__((always_inline)) {
+                constexpr int N = decltype(ntag)::value;
+                if constexpr (MB == 4)
+                    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.ax), "+v"(f.bx) : "n"(N));
+                else if constexpr (MB == 3)
+                    asm volatile("s_waitcnt lgkmcnt(%7)" : "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.ax), "+v"(f.bx) : "n"(N));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.b[0]), "+v"(f.b[1]), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.ax), "+v"(f.bx) : "n"(N));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto mm = [&](const Frag& f) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+                if constexpr (EXTRA) accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ax, f.bx, accx, 0, 0, 0);
+            };
+            Frag f0, f1;
+            if constexpr (!EXTRA) {  // never read in this variant: give the named registers a value
+                f0.ax = f0.bx = f1.ax = f1.bx = bf16x8{};
+            }
+            auto ktile = [&](unsigned partag, bool dma, int dbuf, int dk0) __attribute__((always_inline)) {
+                auto dmas = [&](auto kstag) __attribute__((always_inline)) {
+                    constexpr int ks = decltype(kstag)::value;
+                    if (dma) {
+                        piece(std::integral_constant<int, ks * PPK + 0>{}, dbuf, dk0);
+                        if constexpr (PPK > 1) piece(std::integral_constant<int, ks * PPK + 1>{}, dbuf, dk0);
+                        if constexpr (PPK > 2) piece(std::integral_constant<int, ks * PPK + 2>{}, dbuf, dk0);
+                    }
+                };
+                issue(std::integral_constant<int, 0>{}, partag, f0);
+                issue(std::integral_constant<int, 1>{}, partag, f1);
+                settle(std::integral_constant<int, NR>{}, f0);
+                mm(f0);
+                dmas(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                issue(std::integral_constant<int, 2>{}, partag, f0);
+                settle(std::integral_constant<int, NR>{}, f1);
+                mm(f1);
+                dmas(std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                issue(std::integral_constant<int, 3>{}, partag, f1);
+                settle(std::integral_constant<int, NR>{}, f0);
+                mm(f0);
+                dmas(std::integral_constant<int, 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+                settle(std::integral_constant<int, 0>{}, f1);
+                mm(f1);
+            };
+            for (int t = 0; t < nkt; ++t) {
+                if (t == 0) vmwait_rt(kt1 ? pend + pieces : pend);
+                else if (t == 1 && kt1) vmwait_rt(pend);
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                bool dma = false;
+                int dbuf = 0, dk0 = 0;
+                if (t + 1 < nkt) {
+                    if (!(t == 0 && kt1)) { dma = true; dbuf = (t + 1) & 1; dk0 = (t + 1) * 64; }
+                } else if (more) {
+                    setup();
+                    dma = true;
+                }
+                ktile((unsigned)((t & 1) * STAGE), dma, dbuf, dk0);
+            }
+#undef LDSR
+        };
+        if constexpr (IL == 7) {
+            if (extra) kloop7(std::true_type{});
+            else kloop7(std::false_type{});
+        } else
         if constexpr (IL == 6) {
             if (extra) kloop6(std::true_type{});
             else kloop6(std::false_type{});
@@ -722,19 +828,19 @@ int main(int argc, char** argv) {
     compare("big2 MB=" #MB " IL=" #IL " ST=" #ST " PR=" #PR);
 #define TIMEV(MB, ABL, IL, ST, PR) time_us([&] { launch_big2<MB, ABL, IL, ST, PR>(A, B, bias, C, M, N, K, nullptr); }, 20)
     if (N == 768) {
-        CHECKV(3, 1, 2, 0) CHECKV(3, 5, 2, 0) CHECKV(3, 6, 2, 0)
+        CHECKV(3, 1, 2, 0) CHECKV(3, 7, 2, 0) CHECKV(2, 7, 2, 0)
         for (int r = 0; r < rounds; ++r) {
             const float t0 = time_us([&] { spv_gemm_nt(A, B, bias, Cref, M, N, K, K, K, N, SPV_BF16, SPV_BF16, 0, 1, nullptr, nullptr); }, 20);
-            const float a = TIMEV(3, 0, 1, 2, 0), b = TIMEV(3, 0, 5, 2, 0), c = TIMEV(3, 0, 6, 2, 0), d = TIMEV(3, 1, 1, 2, 0), e = TIMEV(3, 1, 5, 2, 0), f = TIMEV(3, 1, 6, 2, 0);
-            printf("round %d: product %6.2f | MB=3 IL1 %6.2f  IL5 %6.2f | IL6 %6.2f | MB=3 no store: IL1 %6.2f IL5 %6.2f  IL6 %6.2f\n", r, t0, a, b, c, d, e, f);
+            const float a = TIMEV(3, 0, 1, 2, 0), b = TIMEV(3, 0, 7, 2, 0), c = TIMEV(2, 0, 7, 2, 0), d = TIMEV(3, 1, 1, 2, 0), e = TIMEV(3, 1, 7, 2, 0), f = TIMEV(3, 7, 7, 2, 0);
+            printf("round %d: product %6.2f | MB=3 IL1 %6.2f  IL7 %6.2f | MB=2 IL7 %6.2f | MB=3 no store: IL1 %6.2f IL7 %6.2f  IL7 no dma %6.2f\n", r, t0, a, b, c, d, e, f);
             fflush(stdout);
         }
     } else {
-        CHECKV(4, 1, 2, 0) CHECKV(4, 5, 2, 0) CHECKV(4, 6, 2, 0)
+        CHECKV(4, 1, 2, 0) CHECKV(4, 7, 2, 0) CHECKV(2, 7, 2, 0)
         for (int r = 0; r < rounds; ++r) {
             const float t0 = time_us([&] { spv_gemm_nt(A, B, bias, Cref, M, N, K, K, K, N, SPV_BF16, SPV_BF16, 0, 1, nullptr, nullptr); }, 20);
-            const float a = TIMEV(4, 0, 1, 2, 0), b = TIMEV(4, 0, 5, 2, 0), c = TIMEV(4, 0, 6, 2, 0), d = TIMEV(4, 1, 1, 2, 0), e = TIMEV(4, 1, 5, 2, 0), f = TIMEV(4, 1, 6, 2, 0);
-            printf("round %d: product %6.2f | MB=4 IL1 %6.2f  IL5 %6.2f | IL6 %6.2f | MB=4 no store: IL1 %6.2f IL5 %6.2f  IL6 %6.2f\n", r, t0, a, b, c, d, e, f);
+            const float a = TIMEV(4, 0, 1, 2, 0), b = TIMEV(4, 0, 7, 2, 0), c = TIMEV(2, 0, 7, 2, 0), d = TIMEV(4, 1, 1, 2, 0), e = TIMEV(4, 1, 7, 2, 0), f = TIMEV(4, 7, 7, 2, 0);
+            printf("round %d: product %6.2f | MB=4 IL1 %6.2f  IL7 %6.2f | MB=2 IL7 %6.2f | MB=4 no store: IL1 %6.2f IL7 %6.2f  IL7 no dma %6.2f\n", r, t0, a, b, c, d, e, f);
             fflush(stdout);
         }
     }
