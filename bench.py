@@ -77,7 +77,14 @@ def attach_pmc_traffic(roof, mixer):
     if roof["kernel"] == "gemm":
         M, N, K = roof["shape"]
         nt_grid = ((M + 127) // 128) * ((N + 127) // 128) * 256
-        cands = [e for e in data["kernels"] if e["kernel"].startswith("gemm_nt") and e["grid_size"] == nt_grid]
+        cands = []
+        if N % 256 == 0 and N <= 2048 and K % 128 == 0 and M >= 8192:
+            # the strip kernel (spv_gemm.hip strip_plan): min(256 // strips, row blocks) row groups x strips workgroups of 512
+            strips = N // 256
+            strip_grid = min(256 // strips, (M + 31) // 32) * strips * 512
+            cands += [e for e in data["kernels"] if e["kernel"].startswith("gemm_nt_strip") and e["grid_size"] == strip_grid
+                      and e["kernel"].endswith("false>")]
+        cands += [e for e in data["kernels"] if e["kernel"].startswith("gemm_nt_kernel") and e["grid_size"] == nt_grid]
         cands += [e for e in data["kernels"] if e["kernel"].startswith("gemm_tn") and e["grid_size"] % nt_grid == 0 and K > 4096]
     else:
         B = roof["shape"][0]
