@@ -70,6 +70,10 @@ int spv_gemm_nt_grouped_rows(const void* A, const void* B, const float* bias, co
 int spv_gemm_nt_pool_bwd(const void* A, const void* B, void* C, const void* dout, int pool_window, int M, int N, int K,
                          int lda, int ldb, int ldc, int in_dtype, int out_dtype, int dout_dtype, void* stream);
 
+/* Multi-GPU runs: keep n CUs (0..128) free of the one-workgroup-per-CU layer GEMM (it needs a whole CU, so a CU that holds a resident
+ * RCCL channel would push its workgroup into a second dispatch round).  spectre_vit.dp.GradReducer sets 16 when world_size > 1; the
+ * reference has no counterpart (single device, train.py:41). */
+int spv_set_reserved_cus(int n);
 /* TN contraction C[M,N] = sum_k A[k][m] B[k][n], A [K,lda>=M], B [K,ldb>=N] row-major bf16: the weight gradient
  * dW = dh^T . x (backward of layers.py:86) straight from the row-major activations (transposing LDS reads,
  * ds_read_b64_tr_b16); M, N, lda, ldb multiples of 8; split-K as above. */

@@ -97,6 +97,27 @@ def test_gemm_nt_strip_kernel(ops, M, N, K):
     assert torch.equal(C2, (C32b + C0.float()).to(torch.bfloat16)), "strip kernel accumulate differs"
 
 
+def test_gemm_nt_strip_kernel_with_reserved_cus(ops):
+    """spv_set_reserved_cus (multi-GPU runs leave CUs to RCCL) changes the row shares, not the numbers."""
+    from spectre_vit import _native
+    M, N, K = 33280, 768, 512
+    g = torch.Generator(device="cpu").manual_seed(5)
+    A = (torch.randn((M, K), generator=g) * 0.5).to(dev()).to(torch.bfloat16)
+    B = (torch.randn((N, K), generator=g) * 0.1).to(dev()).to(torch.bfloat16)
+    C0 = torch.empty((M, N), dtype=torch.bfloat16, device=dev())
+    ops._gemm(A, B, None, C0, M, N, K, K, K, N, 0, 1, None)
+    try:
+        for reserve in (16, 40, 128):
+            _native.call("spv_set_reserved_cus", reserve)
+            C1 = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=dev())
+            ops._gemm(A, B, None, C1, M, N, K, K, K, N, 0, 1, None)
+            assert torch.equal(C0, C1), f"reserve {reserve}"
+    finally:
+        _native.call("spv_set_reserved_cus", 0)
+    with pytest.raises(RuntimeError):
+        _native.call("spv_set_reserved_cus", 200)
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(128, 128, 64, 1), (768, 512, 33280, 12), (104, 48, 1000, 3), (512, 8192, 2600, 2),
                                           (8, 16, 40, 1), (264, 136, 4100, 5)])
 def test_gemm_tn(ops, M, N, K, splits):

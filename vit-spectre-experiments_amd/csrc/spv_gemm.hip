@@ -729,12 +729,18 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
 
 // the uneven shares of the strip kernel: `groups` row groups of base (+1 for the first rem) 32-row blocks; picks the
 // wave-row height MB whose sub-tiles (2 MB or 2 MB + 1 blocks) cover base and base + 1 without padding
+// CUs the strip kernel leaves alone (spv_set_reserved_cus): a strip workgroup needs a whole CU (2 x 256 VGPRs per SIMD, 155 KiB of
+// LDS), so on a CU that holds a resident RCCL channel it cannot start and would run as a second dispatch round.  16 reserved CUs cost
+// nothing at the layer shapes (the largest share stays 9 / 13 row blocks).
+static int g_reserved_cus = 0;
+
 inline bool strip_plan(int M, int N, int K, int& MB, int& nstrips, int& groups, int& base, int& rem) {
     static const int enabled = getenv("SPV_GEMM_STRIP") ? atoi(getenv("SPV_GEMM_STRIP")) : 1;
     if (!enabled || N % 256 != 0 || N > 2048 || K % 128 != 0 || K < 128 || M < 8192) return false;
     nstrips = N / 256;
     const int nblk = cdiv(M, 32);
-    groups = 256 / nstrips;
+    groups = (256 - g_reserved_cus) / nstrips;
+    if (groups < 1) return false;
     if (groups > nblk) groups = nblk;
     base = nblk / groups;
     rem = nblk % groups;
@@ -1009,6 +1015,12 @@ reduce:
 static int gemm_entry(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int in_dtype, int out_dtype, int accumulate, int splits, void* workspace, void* stream, int rg, int gs,
                       int roff, const float* bias2d, const void* bc = nullptr, int bc_pw = 0, int bc_bf = 0);
+
+extern "C" int spv_set_reserved_cus(int n) {
+    SPV_CHECK(n >= 0 && n <= 128, "spv_set_reserved_cus: %d outside 0..128", n);
+    g_reserved_cus = n;
+    return 0;
+}
 
 extern "C" int spv_gemm_nt_pool_bwd(const void* A, const void* B, void* C, const void* dout, int pool_window, int M, int N, int K,
                                     int lda, int ldb, int ldc, int in_dtype, int out_dtype, int dout_dtype, void* stream) {

@@ -20,6 +20,9 @@ import torch
 import torch.distributed as dist
 
 
+RESERVED_CUS = 16  # CUs left to RCCL while gradients are exchanged during the backward (bench.py caps RCCL's channels to match)
+
+
 class GradReducer:
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 8.0, process_group=None, reduce_dtype=None,
                  tail_mb: float = 2.0):
@@ -33,6 +36,14 @@ class GradReducer:
         self._bucket_of = {}
         if not self.params or self.world == 1:
             return  # single process: no exchange, gradients stay ordinary per-parameter tensors
+        if self.params[0].is_cuda:
+            # the layer GEMMs run one workgroup per CU and cannot share a CU with a resident RCCL channel: leave 16 CUs to the
+            # collectives that overlap the backward (free at the layer shapes, see spv.h: spv_set_reserved_cus)
+            try:
+                from spectre_vit import _native
+                _native.call("spv_set_reserved_cus", RESERVED_CUS)
+            except Exception:  # model-agnostic reducer on a stock model without the library
+                pass
         try:
             from spectre_vit.hip_ops import GradSink
         except Exception:  # the reducer itself is model agnostic (CPU gloo tests use a stock model)
