@@ -103,14 +103,12 @@ int64_t spv_rowop_partial_floats(int n);
  * takes the skip gradient of the layer above (linear3, 768 -> 512) at its source: dout_eff = dout + AdaptiveAvgPool1d^T(mask_up * up_src),
  * up_src [rows, 512] = the gradient that entered linear3's tail (`ds` of spv_spectre_tail_ln_bwd), up_p_drop / up_seed = linear3's
  * dropout.  linear3's backward is then called with dx_pool = NULL and its data-gradient GEMM stores instead of accumulating.
- * up_mask (nullable): linear3's drop bits as written by spv_spectre_tail_ln_bwd (drop_mask: rows x 64 bytes, bit c of byte
- * [row][lane] = column 8 lane + c was dropped); NULL: re-derived from up_seed.
  * spv_tail_up_supported: 1 for (n, k_in) = (768, 512). */
 int spv_tail_up_supported(int n, int k_in, int dtype);
 int spv_spectre_tail_bwd_up(const void* dout, const void* h, const float* mean, const float* rstd, const float* gamma,
                             const float* beta, void* dh, void* dx_pool, float* dgamma, float* dbeta, float* dbias, float* partials,
                             int rows, int n, int k_in, int dtype, int dout_dtype, float p_drop, uint64_t seed, const void* dx_add,
-                            const void* up_src, float up_p_drop, uint64_t up_seed, const void* up_mask, void* stream);
+                            const void* up_src, float up_p_drop, uint64_t up_seed, void* stream);
 /* Second half of the encoder layer's elementwise work as ONE kernel each way:
  *   f3 = SpectreLinear3-tail(h3, f1) (as spv_spectre_tail_fwd), x2 = LayerNorm2(x1 + f3)   (spectre.py:67, 70-73)
  * spv_tail_ln_supported: shapes covered (512 outputs from 768 inputs, either dtype); otherwise compose
@@ -120,8 +118,7 @@ int spv_spectre_tail_bwd_up(const void* dout, const void* h, const float* mean, 
  *   bwd: ds = LayerNorm2-backward(dout2) (written: the residual branch needs it) is used at once as the tail's incoming
  *        gradient; dh, dx_pool (NULL: not formed, see spv_spectre_tail_bwd_up), dgamma, dbeta, dbias as spv_spectre_tail_bwd; dgamma2,
  *        dbeta2 of LayerNorm-2;
- *        partials: spv_tail_ln_partial_floats(n) floats; drop_mask (nullable, rows x 64 bytes): the tail's drop bits for
- *        spv_spectre_tail_bwd_up. */
+ *        partials: spv_tail_ln_partial_floats(n) floats. */
 int spv_tail_ln_supported(int n, int k_in, int dtype);
 int64_t spv_tail_ln_partial_floats(int n);
 int spv_spectre_tail_ln_fwd(const void* h, const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
@@ -131,7 +128,7 @@ int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const void* res, 
                             const float* gamma2, void* ds, float* dgamma2, float* dbeta2, const void* h, const float* mean,
                             const float* rstd, const float* gamma, const float* beta, void* dh, void* dx_pool, float* dgamma,
                             float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype, float p_drop,
-                            uint64_t seed, void* drop_mask, void* stream);
+                            uint64_t seed, void* stream);
 
 /* ---- residual + LayerNorm ------------------------------------------------------------------------
  * mode 0: out = LN(a) + b      norm1(mix(x)) + x   spectre_vit/models/spectre/spectre.py:66

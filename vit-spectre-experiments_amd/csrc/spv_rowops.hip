@@ -606,7 +606,6 @@ struct TailLn2 {
     const void* dout2;      // backward: gradient wrt x2
     const void* f3;         // backward: the tail's forward output
     void* ds;               // backward: gradient wrt (x1 + f3), also needed by the residual branch
-    unsigned char* drop_mask;  // backward, nullable: one byte per lane and row, bit c = this lane's column c was dropped (for TailUp)
 };
 __device__ __forceinline__ float round_store(float v, int bf) { return bf ? bf2f(f2bf(v)) : v; }
 
@@ -693,7 +692,6 @@ struct TailUp {
     const void* src;
     float p_drop;
     uint64_t seed;
-    const unsigned char* mask;  // nullable: that layer's drop bits as written by its backward (saves re-deriving them by hash)
 };
 
 // Column sums (dgamma, dbeta, dbias) live in LDS, not registers: 3*CO accumulators per lane pushed the register count
@@ -761,16 +759,10 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
                 float u[CI];
                 ld_span<CI>(up.src, (size_t)row * k_in + lane * CI, bf, u);
                 if (up.p_drop > 0.0f) {
+                    const unsigned ukey = dropout_row_key(up.seed, (uint64_t)row);
                     const float uinv = 1.0f / (1.0f - up.p_drop);
-                    if (up.mask != nullptr) {
-                        const unsigned m = up.mask[(size_t)row * 64 + lane];
 #pragma unroll
-                        for (int c = 0; c < CI; ++c) u[c] = ((m >> c) & 1u) ? 0.0f : u[c] * uinv;
-                    } else {
-                        const unsigned ukey = dropout_row_key(up.seed, (uint64_t)row);
-#pragma unroll
-                        for (int c = 0; c < CI; ++c) u[c] *= dropout_scale(ukey, (unsigned)(lane * CI + c), up.p_drop, uinv);
-                    }
+                    for (int c = 0; c < CI; ++c) u[c] *= dropout_scale(ukey, (unsigned)(lane * CI + c), up.p_drop, uinv);
                 }
 #pragma unroll
                 for (int j = 0; j < CO; ++j) {
@@ -784,7 +776,6 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
         }
         ld_span<CO>(h, (size_t)row * n + lane * CO, bf, hv);
         float s1 = 0.0f, s2 = 0.0f;
-        unsigned dropped = 0;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             float g[4], b[4], a0[4], a1[4];
@@ -793,11 +784,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * q + e;
-                if (p_drop > 0.0f) {
-                    const float sc = dropout_scale(rkey, (unsigned)(lane * CO + c), p_drop, inv_keep);
-                    dv[c] *= sc;
-                    if (LN2 && sc == 0.0f) dropped |= 1u << c;
-                }
+                if (p_drop > 0.0f) dv[c] *= dropout_scale(rkey, (unsigned)(lane * CO + c), p_drop, inv_keep);
                 const float xhat = (hv[c] - mean) * rstd;
                 float dgel, unused;
                 if (FASTG) gelu_fast(xhat * g[e] + b[e], unused, dgel);
@@ -817,7 +804,6 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
             accw[(1 * Q + q) * 64] = v1;
             __builtin_amdgcn_sched_barrier(0);  // keep the chunks sequential: interleaving them only adds live registers
         }
-        if (LN2 && CO <= 8 && ln.drop_mask != nullptr) ln.drop_mask[(size_t)row * 64 + lane] = (unsigned char)dropped;
         const float m1 = wave_sum(s1) / (float)n, m2 = wave_sum(s2) / (float)n;
         float o[CO];
 #pragma unroll
@@ -995,7 +981,7 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
                                     float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype,
                                     int dout_dtype, float p_drop, uint64_t seed, const void* dx_add, void* stream) {
     return tail_bwd_impl(dout, h, mean, rstd, gamma, beta, dh, dx_pool, dgamma, dbeta, dbias, partials, rows, n, k_in, dtype, dout_dtype,
-                         p_drop, seed, dx_add, stream, TailUp{nullptr, 0.0f, 0, nullptr});
+                         p_drop, seed, dx_add, stream, TailUp{nullptr, 0.0f, 0});
 }
 
 extern "C" int spv_tail_up_supported(int n, int k_in, int dtype) {
@@ -1007,11 +993,11 @@ extern "C" int spv_spectre_tail_bwd_up(const void* dout, const void* h, const fl
                                        const float* beta, void* dh, void* dx_pool, float* dgamma, float* dbeta, float* dbias,
                                        float* partials, int rows, int n, int k_in, int dtype, int dout_dtype, float p_drop,
                                        uint64_t seed, const void* dx_add, const void* up_src, float up_p_drop, uint64_t up_seed,
-                                       const void* up_mask, void* stream) {
+                                       void* stream) {
     SPV_CHECK(up_src != nullptr && spv_tail_up_supported(n, k_in, dtype), "spv_spectre_tail_bwd_up: unsupported shape %d -> %d", k_in, n);
     SPV_CHECK(up_p_drop >= 0.0f && up_p_drop < 1.0f, "spv_spectre_tail_bwd_up: up_p_drop=%f", up_p_drop);
     return tail_bwd_impl(dout, h, mean, rstd, gamma, beta, dh, dx_pool, dgamma, dbeta, dbias, partials, rows, n, k_in, dtype, dout_dtype,
-                         p_drop, seed, dx_add, stream, TailUp{up_src, up_p_drop, up_seed, static_cast<const unsigned char*>(up_mask)});
+                         p_drop, seed, dx_add, stream, TailUp{up_src, up_p_drop, up_seed});
 }
 
 // ---- linear3 tail + residual + LayerNorm-2 as one kernel each way (512 outputs from 768 inputs: the lane-contiguous <8, 12> kernels)
@@ -1028,7 +1014,7 @@ extern "C" int spv_spectre_tail_ln_fwd(const void* h, const void* x, const float
     SPV_CHECK(p_drop >= 0.0f && p_drop < 1.0f, "spv_spectre_tail_ln_fwd: p_drop=%f", p_drop);
     SPV_CHECK(h && x && gamma && beta && out && mean && rstd && res && gamma2 && beta2 && out2 && mean2 && rstd2, "spv_spectre_tail_ln_fwd: null pointer");
     const int bfl = dtype == SPV_BF16;
-    TailLn2 ln{res, gamma2, beta2, out2, mean2, rstd2, nullptr, nullptr, nullptr, nullptr};
+    TailLn2 ln{res, gamma2, beta2, out2, mean2, rstd2, nullptr, nullptr, nullptr};
     dim3 lgrid(std::min(cdiv(rows, RW), 2048));
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bfl) hipLaunchKernelGGL((tail_fwd_lc_kernel<8, 12, true, true>), lgrid, dim3(RT), 0, st, h, x, gamma, beta, out, mean, rstd, rows, bfl, bfl, p_drop, seed, ln);
@@ -1041,18 +1027,18 @@ extern "C" int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const 
                                        const float* gamma2, void* ds, float* dgamma2, float* dbeta2, const void* h, const float* mean,
                                        const float* rstd, const float* gamma, const float* beta, void* dh, void* dx_pool, float* dgamma,
                                        float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype, float p_drop,
-                                       uint64_t seed, void* drop_mask, void* stream) {
+                                       uint64_t seed, void* stream) {
     SPV_CHECK(rows > 0 && spv_tail_ln_supported(n, k_in, dtype), "spv_spectre_tail_ln_bwd: unsupported shape %d -> %d / dtype %d", k_in, n, dtype);
     SPV_CHECK(dout2 && f3 && res && mean2 && rstd2 && gamma2 && ds && dgamma2 && dbeta2 && h && mean && rstd && gamma && beta && dh &&
                   dgamma && dbeta && dbias && partials,
               "spv_spectre_tail_ln_bwd: null pointer");
     const int bfl = dtype == SPV_BF16;
-    TailLn2 ln{res, gamma2, nullptr, nullptr, const_cast<float*>(mean2), const_cast<float*>(rstd2), dout2, f3, ds, static_cast<unsigned char*>(drop_mask)};
+    TailLn2 ln{res, gamma2, nullptr, nullptr, const_cast<float*>(mean2), const_cast<float*>(rstd2), dout2, f3, ds};
     const int lwgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
     const size_t lds = (size_t)RW * 5 * n * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (bfl) hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, true, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln, TailUp{nullptr, 0.0f, 0, nullptr});
-    else hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, false, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln, TailUp{nullptr, 0.0f, 0, nullptr});
+    if (bfl) hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, true, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln, TailUp{nullptr, 0.0f, 0});
+    else hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, false, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln, TailUp{nullptr, 0.0f, 0});
     SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd");
     hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(5 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, lwgs, 5, n, dgamma2, dbeta2);
     SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd(fold)");

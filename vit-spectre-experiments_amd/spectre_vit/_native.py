@@ -33,11 +33,11 @@ SIGNATURES = {
                              c_i, c_f, c_u64, c_vp, c_vp],
     "spv_rowop_partial_floats": [c_i],
     "spv_tail_up_supported": [c_i, c_i, c_i],
-    "spv_spectre_tail_bwd_up": [c_vp] * 12 + [c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_vp, c_vp, c_f, c_u64, c_vp, c_vp],
+    "spv_spectre_tail_bwd_up": [c_vp] * 12 + [c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_vp, c_vp, c_f, c_u64, c_vp],
     "spv_tail_ln_supported": [c_i, c_i, c_i],
     "spv_tail_ln_partial_floats": [c_i],
     "spv_spectre_tail_ln_fwd": [c_vp] * 13 + [c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],
-    "spv_spectre_tail_ln_bwd": [c_vp] * 20 + [c_i, c_i, c_i, c_i, c_f, c_u64, c_vp, c_vp],
+    "spv_spectre_tail_ln_bwd": [c_vp] * 20 + [c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],
     "spv_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_add_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],

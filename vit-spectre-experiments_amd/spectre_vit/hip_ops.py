@@ -375,7 +375,7 @@ def _sl_backward(dout2, saved, need_dx=True, dx_add=None, up=None):
     if up is not None:
         _native.call("spv_spectre_tail_bwd_up", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
                      _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
-                     _p(dx_add) if need_dx else 0, _p(up[0]), float(up[1]), int(up[2]), _p(up[3]), _stream())
+                     _p(dx_add) if need_dx else 0, _p(up[0]), float(up[1]), int(up[2]), _stream())
     else:
         _native.call("spv_spectre_tail_bwd", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
                      _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
@@ -935,15 +935,13 @@ class FFResidualFn(torch.autograd.Function):
             # linear3's skip gradient (its transposed pooling) is taken by linear1's tail backward from `ds` itself when the
             # shapes allow: df1 is then a plain GEMM output (no [rows, 768] tensor written here and re-read by the GEMM)
             defer = _native.call("spv_tail_up_supported", s1[9], s1[10], _dt(h3)) and s1[9] == k
-            # linear3's drop bits, one byte per lane and row: linear1's backward reads them instead of re-hashing
-            mask3 = torch.empty((rows, 64), dtype=torch.uint8, device=dev) if defer and p_drop > 0.0 else None
             _native.call("spv_spectre_tail_ln_bwd", _p(d2), _p(f3), _p(x1), _p(mean2), _p(rstd2), _p(n2w), _p(ds), _p(dn2w), _p(dn2b),
                          _p(h3), _p(mean3), _p(rstd3), _p(g3), _p(be3), _p(dh3), 0 if defer else _p(df1), _p(dg3), _p(dbe3), _p(db3),
-                         _p(partials), rows, n, k, _dt(h3), p_drop, seed, _p(mask3), _stream())
+                         _p(partials), rows, n, k, _dt(h3), p_drop, seed, _stream())
             dw3 = _weight_grad(dh3, f1, rows, n, k, s_w)
             _gemm(dh3, wt3, None, df1, rows, k, n, n, wt3.shape[1], k, accumulate=0 if defer else 1)
             if defer:
-                dx1, dw1, db1, dg1, dbe1 = _sl_backward(df1, s1, True, dx_add=ds, up=(ds, p_drop, seed, mask3))
+                dx1, dw1, db1, dg1, dbe1 = _sl_backward(df1, s1, True, dx_add=ds, up=(ds, p_drop, seed))
                 join_side_stream()
                 return dx1.reshape(ctx.shape), dw1, db1, dg1, dbe1, dw3, db3, dg3, dbe3, dn2w, dn2b, None
         else:
