@@ -137,6 +137,14 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
 __device__ __forceinline__ unsigned dropout_row_key(uint64_t seed, uint64_t row) {
     return mix32((unsigned)seed + (unsigned)row * 0x9e3779b1u) ^ mix32((unsigned)(seed >> 32) + (unsigned)(row >> 32));
 }
+// the same mask for column first_col + c when key_base = row_key + (first_col >> 1) * 0x9e3779b1u (first_col even) and c is a
+// compile-time offset: the per-pair constant folds into an add with a literal instead of a loop-invariant register per
+// pair (the lane-contiguous tail kernels carried ten of those across their row loop and spilled)
+__device__ __forceinline__ float dropout_scale_at(unsigned key_base, int c, float p, float inv_keep) {
+    const unsigned h = mix32(key_base + (unsigned)(c >> 1) * 0x9e3779b1u);
+    const unsigned u16 = (c & 1) ? (h >> 16) : (h & 0xffffu);
+    return u16 < (unsigned)(p * 65536.0f + 0.5f) ? 0.0f : inv_keep;
+}
 __device__ __forceinline__ float dropout_scale(unsigned row_key, unsigned col, float p, float inv_keep) {
     // one finaliser per PAIR of columns, 16 bits each (drop probability quantised to 1/65536)
     const unsigned h = mix32(row_key + (col >> 1) * 0x9e3779b1u);

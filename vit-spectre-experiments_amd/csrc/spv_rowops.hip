@@ -636,6 +636,7 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
         for (int c = 0; c < CO; ++c) { const float d = hv[c] - mean; q += d * d; }
         const float rstd = rsqrtf(wave_sum(q) / (float)n + LN_EPS);
         const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
+        const unsigned lane_gold = (unsigned)(lane * (CO / 2)) * 0x9e3779b1u;  // this lane's first column pair in the mask hash
         float o[CO];
 #pragma unroll
         for (int c = 0; c < CO; c += 2) {  // column pairs: packed fp32 math
@@ -656,8 +657,8 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
             o[c] = act.x + pv[0];
             o[c + 1] = act.y + pv[1];
             if (p_drop > 0.0f) {
-                o[c] *= dropout_scale(rkey, (unsigned)(lane * CO + c), p_drop, inv_keep);
-                o[c + 1] *= dropout_scale(rkey, (unsigned)(lane * CO + c + 1), p_drop, inv_keep);
+                o[c] *= dropout_scale_at(rkey + lane_gold, c, p_drop, inv_keep);
+                o[c + 1] *= dropout_scale_at(rkey + lane_gold, c + 1, p_drop, inv_keep);
             }
         }
         st_span<CO>(out, (size_t)row * n + lane * CO, out_bf, o);
@@ -717,6 +718,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
     for (int row = wave_g; row < rows; row += nwaves) {
         const float mean = mean_i[row], rstd = rstd_i[row];
         const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
+        const unsigned lane_gold = (unsigned)(lane * (CO / 2)) * 0x9e3779b1u;  // this lane's first column pair in the mask hash
         float hv[CO], dv[CO], dxh[CO];
         if (LN2) {
             // incoming gradient = LayerNorm-2 backward of dout2 at s = x1 + f3, formed here instead of by a separate kernel
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
                     const unsigned ukey = dropout_row_key(up.seed, (uint64_t)row);
                     const float uinv = 1.0f / (1.0f - up.p_drop);
 #pragma unroll
-                    for (int c = 0; c < CI; ++c) u[c] *= dropout_scale(ukey, (unsigned)(lane * CI + c), up.p_drop, uinv);
+                    for (int c = 0; c < CI; ++c) u[c] *= dropout_scale_at(ukey + (unsigned)(lane * (CI / 2)) * 0x9e3779b1u, c, up.p_drop, uinv);
                 }
 #pragma unroll
                 for (int j = 0; j < CO; ++j) {
@@ -784,7 +786,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int c = 4 * q + e;
-                if (p_drop > 0.0f) dv[c] *= dropout_scale(rkey, (unsigned)(lane * CO + c), p_drop, inv_keep);
+                if (p_drop > 0.0f) dv[c] *= dropout_scale_at(rkey + lane_gold, c, p_drop, inv_keep);
                 const float xhat = (hv[c] - mean) * rstd;
                 float dgel, unused;
                 if (FASTG) gelu_fast(xhat * g[e] + b[e], unused, dgel);
