@@ -132,7 +132,7 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            # the layer GEMMs leave 16 CUs to RCCL (spectre_vit.dp.RESERVED_CUS); keep RCCL inside them.  One step exchanges 88 MB
+            # the layer GEMMs leave 16 CUs to RCCL (spectre_vit.dp.RESERVED_CUS); keep RCCL inside them.  One step exchanges 80 MB
             # of fp32 gradients, which 16 channels move well inside the backward.  An explicit NCCL_MAX_NCHANNELS wins.
             os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
             dist.init_process_group("nccl", device_id=dev)
