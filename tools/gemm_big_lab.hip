@@ -184,6 +184,13 @@ static int launch_big(const bf16_t* A, const bf16_t* B, const float* bias, bf16_
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
+__device__ unsigned long long* g_stamps = nullptr;  // ABL & 8: per (workgroup, wave 0 / wave 4) 64 slots
+__device__ __forceinline__ unsigned long long big_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 __device__ __forceinline__ void vmwait_rt(int n) {
     switch (n) {
 #define VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
@@ -302,6 +309,9 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
         const bool extra = s_extra;
         const bool more = cnt > 0;
         const int pieces = MB + 4 + ((extra && (IL == 3 || wave < 4)) ? 1 : 0);
+        const bool rec = (ABL & 8) && lane == 0 && (wave & 3) == 0 && c_m0 == (g * base + min(g, rem)) * 32;  // first sub-tile only
+        unsigned long long* my = (ABL & 8) ? g_stamps + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 : nullptr;
+        if (rec) { my[62] = __builtin_amdgcn_s_memrealtime(); my[63] = big_now(); }
         f32x16 acc[MB][2], accx;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -480,10 +490,13 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
             else kloop6(std::false_type{});
         } else
         for (int t = 0; t < nkt; ++t) {
+            if (rec && t < 8) my[7 * t + 0] = big_now();
             if (t == 0) vmwait_rt(kt1 ? pend + pieces : pend);
             else if (t == 1 && kt1) vmwait_rt(IL == 4 ? pend + pieces : pend);
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (rec && t < 8) my[7 * t + 1] = big_now();
             __builtin_amdgcn_s_barrier();
+            if (rec && t < 8) my[7 * t + 2] = big_now();
             bool dma = false;
             int dbuf = 0, dk0 = 0;
             if (t + 1 < nkt) {
@@ -510,11 +523,33 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
                     bx4 = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
                 }
                 if constexpr (PR == 2) __builtin_amdgcn_s_setprio(1);
+                if constexpr (IL == 8) {
+                    // one DMA piece behind every MFMA pair (pinned): the pieces of all eight waves no longer reach the L1 path
+                    // in one burst after each k-step
+                    auto pair = [&](auto itag) __attribute__((always_inline)) {
+                        constexpr int i = decltype(itag)::value;
+                        if constexpr (i < MB) {
+                            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[0], acc[i][0], 0, 0, 0);
+                            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[1], acc[i][1], 0, 0, 0);
+                            constexpr int P = ks * MB + i;  // piece index: MB per k-step
+                            if constexpr (P < MB + 5) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (dma) piece(std::integral_constant<int, P>{}, dbuf, dk0);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    };
+                    pair(std::integral_constant<int, 0>{});
+                    pair(std::integral_constant<int, 1>{});
+                    pair(std::integral_constant<int, 2>{});
+                    pair(std::integral_constant<int, 3>{});
+                } else {
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
                 if constexpr (PR == 2) __builtin_amdgcn_s_setprio(0);
                 if constexpr (IL == 4) {
                     constexpr int PPK4 = (MB + 4 + 2) / 3;
@@ -532,13 +567,18 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
                     const bf16x8 bx = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
                     accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax, bx, accx, 0, 0, 0);
                 }
-                if constexpr (IL != 0 && ks < 3) {
+                if constexpr (IL != 0 && IL != 8 && ks < 3) {
                     if (dma) {
                         piece(std::integral_constant<int, ks * PPK + 0>{}, dbuf, dk0);
                         if constexpr (PPK > 1) piece(std::integral_constant<int, ks * PPK + 1>{}, dbuf, dk0);
                         if constexpr (PPK > 2) piece(std::integral_constant<int, ks * PPK + 2>{}, dbuf, dk0);
                     }
                     if constexpr (IL == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr ((ABL & 8) != 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (rec && t < 8) my[7 * t + 3 + ks] = big_now();
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             };
             if constexpr (IL == 5) {
@@ -656,6 +696,7 @@ __global__ __launch_bounds__(512) void big2_kernel(const bf16_t* __restrict__ A,
                 }
             }
         }
+        if (rec) { my[60] = big_now(); my[61] = __builtin_amdgcn_s_memrealtime(); }
         kt1 = false;
         if (PRE1 && more) {
             __builtin_amdgcn_s_barrier();   // every wave is done with buffer 1
@@ -827,20 +868,58 @@ int main(int argc, char** argv) {
     launch_big2<MB, 0, IL, ST, PR>(A, B, bias, C, M, N, K, nullptr);  \
     compare("big2 MB=" #MB " IL=" #IL " ST=" #ST " PR=" #PR);
 #define TIMEV(MB, ABL, IL, ST, PR) time_us([&] { launch_big2<MB, ABL, IL, ST, PR>(A, B, bias, C, M, N, K, nullptr); }, 20)
+    {
+        const int NWG = 256;
+        unsigned long long* dst;
+        hipMalloc(&dst, (size_t)NWG * 2 * 64 * 8);
+        hipMemset(dst, 0, (size_t)NWG * 2 * 64 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dst, sizeof(dst));
+        if (N == 768) { launch_big2<3, 8, 1, 2, 0>(A, B, bias, C, M, N, K, nullptr); launch_big2<3, 8, 1, 2, 0>(A, B, bias, C, M, N, K, nullptr); }
+        else { launch_big2<4, 8, 1, 2, 0>(A, B, bias, C, M, N, K, nullptr); launch_big2<4, 8, 1, 2, 0>(A, B, bias, C, M, N, K, nullptr); }
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> hs((size_t)NWG * 2 * 64);
+        hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost);
+        const int nkt = K / 64 < 8 ? K / 64 : 8;
+        const char* names[7] = {"vmcnt wait", "barrier", "k-step 0", "k-step 1", "k-step 2", "k-step 3", "to next top"};
+        for (int grp = 0; grp < 2; ++grp) {
+            std::vector<double> seg[7];
+            std::vector<double> period, clk;
+            for (int w = 0; w < NWG; ++w) {
+                const unsigned long long* my = hs.data() + ((size_t)w * 2 + grp) * 64;
+                if (my[63] == 0) continue;
+                if (my[61] > my[62]) clk.push_back((double)(my[60] - my[63]) / (double)(my[61] - my[62]) * 100.0);
+                for (int t = 1; t < nkt; ++t) {  // skip the first K-tile (prologue latency)
+                    const unsigned long long* q = my + 7 * t;
+                    seg[0].push_back((double)(q[1] - q[0]));
+                    seg[1].push_back((double)(q[2] - q[1]));
+                    for (int k = 0; k < 4; ++k) seg[2 + k].push_back((double)(q[3 + k] - q[2 + k]));
+                    if (t + 1 < nkt) { seg[6].push_back((double)(q[7] - q[6])); period.push_back((double)(q[7] - q[0])); }
+                }
+            }
+            auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+            auto p90 = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() * 9 / 10]; };
+            printf("stamps, wave row %d (s_memtime ticks; median / 90%%): clock %.0f MHz-equivalent | K-tile period %.0f / %.0f |", grp, med(clk), med(period), p90(period));
+            for (int i = 0; i < 7; ++i) printf(" %s %.0f / %.0f |", names[i], med(seg[i]), p90(seg[i]));
+            printf("\n");
+        }
+        unsigned long long* nul = nullptr;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &nul, sizeof(nul));
+        fflush(stdout);
+    }
     if (N == 768) {
-        CHECKV(3, 1, 2, 0) CHECKV(3, 7, 2, 0) CHECKV(2, 7, 2, 0)
+        CHECKV(3, 1, 2, 0) CHECKV(3, 8, 2, 0) CHECKV(2, 8, 2, 0)
         for (int r = 0; r < rounds; ++r) {
             const float t0 = time_us([&] { spv_gemm_nt(A, B, bias, Cref, M, N, K, K, K, N, SPV_BF16, SPV_BF16, 0, 1, nullptr, nullptr); }, 20);
-            const float a = TIMEV(3, 0, 1, 2, 0), b = TIMEV(3, 0, 7, 2, 0), c = TIMEV(2, 0, 7, 2, 0), d = TIMEV(3, 1, 1, 2, 0), e = TIMEV(3, 1, 7, 2, 0), f = TIMEV(3, 7, 7, 2, 0);
-            printf("round %d: product %6.2f | MB=3 IL1 %6.2f  IL7 %6.2f | MB=2 IL7 %6.2f | MB=3 no store: IL1 %6.2f IL7 %6.2f  IL7 no dma %6.2f\n", r, t0, a, b, c, d, e, f);
+            const float a = TIMEV(3, 0, 1, 2, 0), b = TIMEV(3, 0, 8, 2, 0), c = TIMEV(2, 0, 8, 2, 0), d = TIMEV(3, 1, 1, 2, 0), e = TIMEV(3, 1, 8, 2, 0), f = TIMEV(3, 7, 8, 2, 0);
+            printf("round %d: product %6.2f | MB=3 IL1 %6.2f  IL8 %6.2f | MB=2 IL8 %6.2f | MB=3 no store: IL1 %6.2f IL8 %6.2f  IL8 no dma %6.2f\n", r, t0, a, b, c, d, e, f);
             fflush(stdout);
         }
     } else {
-        CHECKV(4, 1, 2, 0) CHECKV(4, 7, 2, 0) CHECKV(2, 7, 2, 0)
+        CHECKV(4, 1, 2, 0) CHECKV(4, 8, 2, 0) CHECKV(2, 8, 2, 0)
         for (int r = 0; r < rounds; ++r) {
             const float t0 = time_us([&] { spv_gemm_nt(A, B, bias, Cref, M, N, K, K, K, N, SPV_BF16, SPV_BF16, 0, 1, nullptr, nullptr); }, 20);
-            const float a = TIMEV(4, 0, 1, 2, 0), b = TIMEV(4, 0, 7, 2, 0), c = TIMEV(2, 0, 7, 2, 0), d = TIMEV(4, 1, 1, 2, 0), e = TIMEV(4, 1, 7, 2, 0), f = TIMEV(4, 7, 7, 2, 0);
-            printf("round %d: product %6.2f | MB=4 IL1 %6.2f  IL7 %6.2f | MB=2 IL7 %6.2f | MB=4 no store: IL1 %6.2f IL7 %6.2f  IL7 no dma %6.2f\n", r, t0, a, b, c, d, e, f);
+            const float a = TIMEV(4, 0, 1, 2, 0), b = TIMEV(4, 0, 8, 2, 0), c = TIMEV(2, 0, 8, 2, 0), d = TIMEV(4, 1, 1, 2, 0), e = TIMEV(4, 1, 8, 2, 0), f = TIMEV(4, 7, 8, 2, 0);
+            printf("round %d: product %6.2f | MB=4 IL1 %6.2f  IL8 %6.2f | MB=2 IL8 %6.2f | MB=4 no store: IL1 %6.2f IL8 %6.2f  IL8 no dma %6.2f\n", r, t0, a, b, c, d, e, f);
             fflush(stdout);
         }
     }

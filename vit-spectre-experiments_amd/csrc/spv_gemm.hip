@@ -425,8 +425,8 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
 //   * a sub-tile is 2*MB row blocks x 256 columns (waves as 2 x 4, wave tile 32*MB x 64) plus an optional extra block
 //     whose 32 x 256 strip is shared out as one 32 x 32 accumulator per wave -- the +-1 block of the uneven shares
 //     costs every wave the same;
-//   * operands are staged by LDS-DMA in 64-deep K-tiles, two buffers, the pieces of K-tile t+1 issued behind the MFMAs
-//     of the first three k-steps of K-tile t (one burst stalls all 8 waves on the 64 B/clk L1 path);
+//   * operands are staged by LDS-DMA in 64-deep K-tiles, two buffers, one piece of K-tile t+1 issued behind every MFMA
+//     pair of K-tile t (bursts stall all 8 waves on the 64 B/clk L1 path);
 //   * the pipeline runs on across sub-tiles: the next sub-tile's first two K-tiles are in flight before the epilogue's
 //     stores are issued, and the waits behind an epilogue are COUNTED (vmcnt retires loads, LDS-DMA and stores in issue
 //     order), so they cover the DMA but not the younger stores;
@@ -531,7 +531,6 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
         piece(std::integral_constant<int, 7>{}, buf, k0);
         piece(std::integral_constant<int, 8>{}, buf, k0);
     };
-    constexpr int PPK = (MB + 5 + 2) / 3;  // pieces issued behind each of the first three k-steps' MFMAs
 
     setup();
     stage(0, 0);
@@ -599,22 +598,30 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
                 for (int f = 0; f < 2; ++f) b[f] = *reinterpret_cast<const bf16x8*>(sp + fb_off + f * 32 * 128 + ch);
 #pragma unroll
                 for (int f = 0; f < MB; ++f) a[f] = *reinterpret_cast<const bf16x8*>(sp + fa_off + f * 32 * 128 + ch);
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                // one DMA piece of the next K-tile behind every MFMA pair (pinned): issued three at a time behind a whole k-step, the
+                // pieces of all eight waves reached the 64 B/clk L1 path together and every wave stood 250-400 clocks in issue
+                // (in-kernel stamps: k-steps with pieces 620-840 clocks, the one without 390)
+                auto pair = [&](auto itag) __attribute__((always_inline)) {
+                    constexpr int i = decltype(itag)::value;
+                    if constexpr (i < MB) {
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[0], acc[i][0], 0, 0, 0);
+                        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[1], acc[i][1], 0, 0, 0);
+                        constexpr int P = ks * MB + i;
+                        if constexpr (P < MB + 5) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (dma) piece(std::integral_constant<int, P>{}, dbuf, dk0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                };
+                pair(std::integral_constant<int, 0>{});
+                pair(std::integral_constant<int, 1>{});
+                pair(std::integral_constant<int, 2>{});
+                pair(std::integral_constant<int, 3>{});
                 if (extra) {
                     const bf16x8 ax = *reinterpret_cast<const bf16x8*>(sp + fax_off + ch);
                     const bf16x8 bx = *reinterpret_cast<const bf16x8*>(sp + fbx_off + ch);
                     accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax, bx, accx, 0, 0, 0);
-                }
-                if constexpr (ks < 3) {
-                    if (dma) {
-                        piece(std::integral_constant<int, ks * PPK + 0>{}, dbuf, dk0);
-                        if constexpr (PPK > 1) piece(std::integral_constant<int, ks * PPK + 1>{}, dbuf, dk0);
-                        if constexpr (PPK > 2) piece(std::integral_constant<int, ks * PPK + 2>{}, dbuf, dk0);
-                    }
                 }
             };
             kstep(std::integral_constant<int, 0>{});
