@@ -97,6 +97,33 @@ def test_gemm_nt_strip_kernel(ops, M, N, K):
     assert torch.equal(C2, (C32b + C0.float()).to(torch.bfloat16)), "strip kernel accumulate differs"
 
 
+def test_gemm_nt_strip_kernel_random_shapes(ops):
+    """Row-share edge cases of the strip kernel (no remainder, all-extra groups, short last sub-tiles, rows not a multiple of 32):
+    a seeded sweep of shapes, bf16 output against the rounding of the 128 x 128 kernel's fp32 output, bit for bit."""
+    rs = np.random.RandomState(20260)
+    g = torch.Generator(device="cpu").manual_seed(77)
+    cases = [(8192 * 2, 256, 128), (23 * 32 * 128, 512, 128), (256 * 9 * 32, 256, 256), (85 * 12 * 32, 768, 128)]
+    for _ in range(10):
+        cases.append((int(rs.randint(8192, 40000)), int(rs.choice([256, 512, 768, 1024, 1536, 2048])), int(rs.choice([128, 256, 384, 640]))))
+    for M, N, K in cases:
+        A = (torch.randn((M, K), generator=g) * 0.5).to(dev()).to(torch.bfloat16)
+        B = (torch.randn((N, K), generator=g) * 0.1).to(dev()).to(torch.bfloat16)
+        bias = torch.randn((N,), generator=g).to(dev())
+        C32 = torch.empty((M, N), dtype=torch.float32, device=dev())
+        ops._gemm(A, B, bias, C32, M, N, K, K, K, N, 0, 1, None)
+        C = torch.full((M + 1, N), 7.0, dtype=torch.bfloat16, device=dev())
+        ops._gemm(A, B, bias, C, M, N, K, K, K, N, 0, 1, None)
+        assert torch.equal(C[:M], C32.to(torch.bfloat16)), f"M={M} N={N} K={K}"
+        assert bool((C[M] == 7.0).all()), f"M={M} N={N} K={K}: wrote past the last row"
+        C0 = torch.randn((M, N), generator=g).to(dev()).to(torch.bfloat16)
+        C2 = C0.clone()
+        ops._gemm(A, B, None, C2, M, N, K, K, K, N, 1, 1, None)
+        C32b = torch.empty((M, N), dtype=torch.float32, device=dev())
+        ops._gemm(A, B, None, C32b, M, N, K, K, K, N, 0, 1, None)
+        assert torch.equal(C2, (C32b + C0.float()).to(torch.bfloat16)), f"M={M} N={N} K={K}: accumulate"
+        del A, B, C32, C, C0, C2, C32b
+
+
 def test_gemm_nt_strip_kernel_with_reserved_cus(ops):
     """spv_set_reserved_cus (multi-GPU runs leave CUs to RCCL) changes the row shares, not the numbers."""
     from spectre_vit import _native
