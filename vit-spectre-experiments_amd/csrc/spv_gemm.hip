@@ -534,8 +534,9 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
 
     setup();
     stage(0, 0);
+    stage(1, 64);          // both buffers are free at the start: the second K-tile's latency overlaps the first one's
     int pend = 0;          // upper bound of the epilogue stores issued after the newest staged K-tile
-    bool kt1 = false;      // the second K-tile of the current sub-tile was staged ahead of the previous epilogue
+    bool kt1 = true;       // the second K-tile of the current sub-tile is already staged (here, or ahead of the previous epilogue)
     while (true) {
         const int c_m0 = s_m0, c_mlim = s_mlim, c_take = s_take;
         const bool extra = s_extra;
