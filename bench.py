@@ -2,15 +2,19 @@
 """Headline benchmark: images/sec of the Spectre-ViT-Small training step (CIFAR-100-shaped synthetic input,
 bs 512 per GPU, bf16) on N MI355X -- BASELINE.json's metric.  One JSON line on stdout (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mixer fft|permut|dwt_embed|dwt_token]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mixer fft|permut|dwt_embed|dwt_token] [--graph]
 
 A step = forward + CrossEntropy + backward + (gradient all-reduce) + AdamW on one batch resident in HBM
-(reference loop: spectre_vit/repl/train.py:216-238).  N > 1: launched by torch.distributed.run, one rank per GPU,
-RCCL all-reduce of the gradients overlapped with backward; weak scaling (512 images per GPU).
+(reference loop: spectre_vit/repl/train.py:216-238).  N > 1: one rank per GPU, RCCL all-reduce of the gradients overlapped
+with backward; weak scaling (512 images per GPU).  ``python bench.py --gpus N`` starts its own ranks (a child
+``torch.distributed.run`` spawned before this process touches the GPU); under an external ``torch.distributed.run`` (WORLD_SIZE
+set) it is one of the ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,43 +28,84 @@ SMALL = dict(img_size=32, patch_size=4, in_channels=3, num_classes=100, embed_di
              hidden_dim=768, dropout=0.001, activation="gelu")
 
 
-def cpu_baseline(mixer, seconds_budget=20.0):
-    """The numpy oracle (a port of the reference's CPU path, validated against it by tests/golden) timed on this
-    host: fp32, same model, same step definition, on a bounded sample (bs 32 per step)."""
-    import numpy as np
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mixer", default="fft", choices=["fft", "permut", "dwt_embed", "dwt_token"])
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--model", default="spectre", choices=["spectre", "vit"],
+                    help="vit = the reference's baseline ViT (MHSA through the HIP attention kernels), not the headline workload")
+    ap.add_argument("--graph", action="store_true",
+                    help="also capture the whole step in a HIP graph and report its replay time next to the eager time")
+    ap.add_argument("--variants", default=None,
+                    help="comma list of other mixers to time for a few steps each and report under \"variants\" "
+                         "(default at 1 GPU with the fft mixer: permut,dwt_embed; 'none' disables)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed steps of the CPU baseline leg (bs = --batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a launcher: start N ranks with torch.distributed.run as a CHILD process (this parent has not
+    imported torch or touched HIP), relay its stdout / stderr and return its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: needed by RCCL on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    child = subprocess.Popen(cmd, env=env, cwd=ROOT)
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        return child.wait()
+
+
+def cpu_baseline(mixer, batch, steps):
+    """The reference's CPU path restated on stock ATen ops (oracle/spectre_torch_cpu.py, pinned to the reference by
+    tests/golden): fp32, same model / mixer / batch size / step definition, timed on this host's cores."""
     import torch
-    from oracle import spectre_oracle as O
+    from oracle import spectre_torch_cpu as T
     from spectre_vit.models.spectre.spectre import SpectreViT
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 128))
+    torch.set_num_threads(threads)
+    if mixer not in ("fft", "permut"):
+        mixer_cpu = "fft"  # the Haar mixers are not restated on ATen ops; same GEMM / row work as the FFT configuration
+    else:
+        mixer_cpu = mixer
     torch.manual_seed(42)
     cfg = dict(SMALL, dropout=0.0)
-    m = SpectreViT(**cfg, mixer=mixer)
-    sd = {k: v.detach().numpy() for k, v in m.state_dict().items()}
-    bs = 32
+    sd = SpectreViT(**cfg, mixer=mixer_cpu).state_dict()
+    st = T.TrainState(sd)
     g = torch.Generator().manual_seed(1234)
-    img = torch.randn(bs, 3, 32, 32, generator=g).numpy()
-    labels = torch.randint(0, 100, (bs,), generator=g).numpy()
-    state = {}
-
-    def step():
-        loss, _, _, grads = O.train_step(img, labels, sd, cfg["num_encoders"], cfg["patch_size"], mixer, np.float32)
-        for k, gk in grads.items():
-            mv = state.setdefault(k, [np.zeros_like(gk), np.zeros_like(gk)])
-            sd[k], mv[0], mv[1] = O.adamw_step(sd[k], gk.astype(np.float32), mv[0], mv[1], 1)
-        return loss
-
-    step()  # warm-up (page in BLAS, build DFT tables)
-    t0 = time.perf_counter()
-    n = 0
-    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 50):
-        step()
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return dict(value=round(bs / dt, 2), unit="images/sec", cores=cores, kind="port",
-                sample=f"numpy fp32 oracle, {n} train steps of bs {bs} (same model/mixer, dropout 0), {dt:.2f} s/step")
+    img = torch.randn(batch, 3, 32, 32, generator=g)
+    labels = torch.randint(0, 100, (batch,), generator=g)
+    st.step(img, labels, cfg["num_encoders"], cfg["patch_size"], mixer_cpu)  # warm-up
+    times = []
+    for _ in range(max(1, steps)):
+        t0 = time.perf_counter()
+        st.step(img, labels, cfg["num_encoders"], cfg["patch_size"], mixer_cpu)
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return dict(value=round(batch / dt, 2), unit="images/sec", cores=threads, kind="port",
+                sample=f"torch-CPU port of the reference step (stock ATen ops + autograd + AdamW, fp32, {mixer_cpu} mixer, dropout 0): "
+                       f"1 warm-up + {len(times)} timed steps of bs {batch}, median {dt:.2f} s/step, {threads} threads of {cores} host cores")
 
 
 def attach_pmc_traffic(roof, mixer):
@@ -74,134 +119,209 @@ def attach_pmc_traffic(roof, mixer):
     if not files:
         return
     data = json.load(open(files[-1]))
-    if roof["kernel"] == "gemm":
-        M, N, K = roof["shape"]
-        nt_grid = ((M + 127) // 128) * ((N + 127) // 128) * 256
-        cands = []
-        if N % 256 == 0 and N <= 2048 and K % 128 == 0 and M >= 8192:
-            # the strip kernel (spv_gemm.hip strip_plan): min(256 // strips, row blocks) row groups x strips workgroups of 512
-            strips = N // 256
-            strip_grid = min(256 // strips, (M + 31) // 32) * strips * 512
-            cands += [e for e in data["kernels"] if e["kernel"].startswith("gemm_nt_strip") and e["grid_size"] == strip_grid
-                      and e["kernel"].endswith("false>")]
-        cands += [e for e in data["kernels"] if e["kernel"].startswith("gemm_nt_kernel") and e["grid_size"] == nt_grid]
-        cands += [e for e in data["kernels"] if e["kernel"].startswith("gemm_tn") and e["grid_size"] % nt_grid == 0 and K > 4096]
-    else:
-        B = roof["shape"][0]
-        cands = [e for e in data["kernels"] if e["kernel"].startswith("fnet_mfma") and e["grid_size"] == B * 512]
+    pats = {"gemm": ("gemm_nt_strip", "gemm_nt_kernel", "gemm_nt_glds"), "gemm_tn": ("gemm_tn", "wgrad"),
+            "gemm_pool_bwd": ("gemm_nt_pool", "gemm_nt_kernel"), "fnet_ln_fwd": ("fnet",), "fnet_ln_bwd": ("fnet",),
+            "fnet_mix": ("fnet",), "tail_fwd": ("tail_fwd",), "tail_bwd": ("tail_bwd",), "tail_bwd_up": ("tail_bwd",),
+            "tail_ln_fwd": ("tail_fwd",), "tail_ln_bwd": ("tail_bwd",), "gather_fwd": ("gather_fwd",), "gather_bwd": ("gather_bwd",)}
+    want = pats.get(roof["kernel"], (roof["kernel"],))
+    # the candidate whose duration in the PMC run is closest to the live bracket
+    cands = [e for e in data.get("kernels", []) if any(e["kernel"].startswith(w) for w in want) and e.get("hbm_bytes_corrected")]
     if cands:
-        roof["traffic"] = cands[0]["hbm_bytes_corrected"]
+        best = min(cands, key=lambda e: abs((e.get("avg_us") or roof["avg_us"]) - roof["avg_us"]))
+        roof["traffic"] = best["hbm_bytes_corrected"]
         roof["traffic_source"] = os.path.basename(files[-1])
+        roof["traffic_kernel"] = best["kernel"][:80]
+
+
+class Job:
+    """model + optimizer + resident batch for one mixer; step() is the measured unit."""
+
+    def __init__(self, args, mixer, dev, rank, stand_in=False):
+        import torch
+        from spectre_vit.dp import GradReducer, broadcast_module
+        self.torch = torch
+        torch.manual_seed(42)
+        if stand_in:  # CPU rehearsal of the launcher / collectives only (no GPU in this process): a small stock model
+            model = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(3 * 32 * 32, 64), torch.nn.GELU(), torch.nn.Linear(64, 100))
+        elif args.model == "vit":
+            from spectre_vit.models.vit.vit import ViT
+            model = ViT(**SMALL).to(dev)
+        else:
+            from spectre_vit.models.spectre.spectre import SpectreViT
+            model = SpectreViT(**SMALL, mixer=mixer).to(dev)
+        broadcast_module(model)
+        model.train()
+        self.model = model
+        torch.manual_seed(1234 + rank)  # per-rank dropout / data streams
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
+        labels = torch.randint(0, 100, (args.batch,), generator=g).to(torch.uint8).to(dev)  # uint8 as train.py:218
+        self.labels = labels.long()
+        self.reducer = GradReducer(model)
+        self.opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, fused=not stand_in)
+        self.crit = torch.nn.CrossEntropyLoss()
+        self.use_bf16 = args.dtype == "bf16" and not stand_in
+        self.dev = dev
+        self.param_bytes = sum(p.numel() for p in model.parameters()) * 4
+        self.timer = None
+
+    def step(self):
+        torch = self.torch
+        self.reducer.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_bf16):
+            out = self.model(self.img)
+        loss = self.crit(out, self.labels)
+        loss.backward()
+        self.reducer.finish()
+        if self.timer is not None:  # fused AdamW reads p, g, m, v and writes p, m, v
+            self.timer.bracket("torch:adamw_fused", (7 * self.param_bytes,), self.opt.step)
+        else:
+            self.opt.step()
+        return loss
+
+
+def timed_region(job, sync, steps, warmup):
+    for _ in range(warmup):
+        job.step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = job.step()
+    sync()
+    return time.perf_counter() - t0, loss
+
+
+def graph_replay(args, mixer, dev, steps, warmup):
+    """The same step captured once in a HIP graph and replayed (single GPU).  Dropout seeds are host-drawn kernel arguments, so a
+    replay would repeat the captured masks: the graph job runs with dropout 0 and the eager time it is compared with is
+    re-measured with dropout 0 as well (the mask hash is ~1 % of the row kernels)."""
+    import torch
+    from spectre_vit import hip_ops
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    torch.manual_seed(42)
+    model = SpectreViT(**dict(SMALL, dropout=0.0), mixer=mixer).to(dev).train()
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
+    labels = torch.randint(0, 100, (args.batch,), generator=g).to(dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, fused=True, capturable=True)
+    crit = torch.nn.CrossEntropyLoss()
+    use_bf16 = args.dtype == "bf16"
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
+            out = model(img)
+        loss = crit(out, labels)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def timeit(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    eager_ms = timeit(step)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    hip_ops._shadows = type(hip_ops._shadows)()  # the weight casts must be recorded, not served from a cache
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        loss = step()
+    graph_ms = timeit(graph.replay)
+    return dict(eager_ms_per_step=round(eager_ms, 3), graph_ms_per_step=round(graph_ms, 3), dropout=0.0,
+                images_per_sec=round(args.batch / graph_ms * 1e3, 1), final_loss=round(float(loss.item()), 4))
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mixer", default="fft", choices=["fft", "permut", "dwt_embed", "dwt_token"])
-    ap.add_argument("--batch", type=int, default=512, help="images per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--model", default="spectre", choices=["spectre", "vit"],
-                    help="vit = the reference's baseline ViT (MHSA through the HIP attention kernels), not the headline workload")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(self_launch(args, argv))  # before torch / HIP are touched in this process
 
     import torch
     import torch.distributed as dist
-    from spectre_vit import hip_ops
-    from spectre_vit.dp import GradReducer, broadcast_module
-    from spectre_vit.models.spectre.spectre import SpectreViT
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    # SPV_BENCH_REHEARSAL=1: all ranks on device 0 over gloo -- lets the multi-rank control flow (collectives, barriers,
-    # rank-0-only sections) be exercised on a one-GPU box; never used for reported numbers
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    # SPV_BENCH_REHEARSAL=1: all ranks on device 0 over gloo -- lets the multi-rank control flow (launcher, collectives, barriers,
+    # rank-0-only sections) be exercised on a one-GPU box; with no GPU at all a small stock model stands in on the CPU, so that
+    # the launcher and the collectives can be tested in the build container.  Never used for reported numbers.
     rehearsal = os.environ.get("SPV_BENCH_REHEARSAL") == "1"
+    stand_in = rehearsal and not torch.cuda.is_available()
     if rehearsal:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if stand_in:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
+            backend = "gloo"
             dist.init_process_group("gloo")
         else:
             # the layer GEMMs leave 16 CUs to RCCL (spectre_vit.dp.RESERVED_CUS); keep RCCL inside them.  One step exchanges 80 MB
             # of fp32 gradients, which 16 channels move well inside the backward.  An explicit NCCL_MAX_NCHANNELS wins.
             os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+            backend = "nccl"
             dist.init_process_group("nccl", device_id=dev)
-
-    torch.manual_seed(42)
-    if args.model == "vit":
-        from spectre_vit.models.vit.vit import ViT
-        model = ViT(**SMALL).to(dev)
-        args.no_cpu_baseline = True  # the CPU leg times the Spectre oracle
-    else:
-        model = SpectreViT(**SMALL, mixer=args.mixer).to(dev)
-    broadcast_module(model)
-    model.train()
-    torch.manual_seed(1234 + rank)  # per-rank dropout / data streams
-    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
-    labels = torch.randint(0, 100, (args.batch,), generator=g).to(torch.uint8).to(dev)  # uint8 as train.py:218
-    labels = labels.long()
-    reducer = GradReducer(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, fused=True)
-    crit = torch.nn.CrossEntropyLoss()
-    use_bf16 = args.dtype == "bf16"
-
-    def step():
-        reducer.zero_grad()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_bf16):
-            out = model(img)
-        loss = crit(out, labels)
-        loss.backward()
-        reducer.finish()
-        opt.step()
-        return loss
+    if args.model == "vit" or stand_in:
+        args.no_cpu_baseline = True  # the CPU leg times the Spectre port
+    if stand_in:
+        args.no_roofline = True
 
     def sync():
-        torch.cuda.synchronize()
+        if not stand_in:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stand_in:
+            torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    sync()
-    elapsed = time.perf_counter() - t0
+    job = Job(args, args.mixer, dev, rank, stand_in)
+    elapsed, loss = timed_region(job, sync, args.steps, args.warmup)
     # roofline pass: the same step, same process, right after the timed region, with HIP events recorded on the launch
-    # stream around every GEMM / FNet-mixer launch.  Kept out of the headline timing because the ~60 event pairs per
-    # step perturb it (measured: 6.3 ms/step bracketed vs 4.9 ms/step clean).
-    # Every rank runs these steps (each one contains the gradient all-reduce: a rank that skipped them would leave the
-    # others waiting in the collective); only rank 0 records events.
+    # stream around EVERY C-ABI launch and the optimizer.  Kept out of the headline timing because the ~100 event pairs per
+    # step perturb it.  Every rank runs these steps (each one contains the gradient all-reduce: a rank that skipped them
+    # would leave the others waiting in the collective); only rank 0 records events.
     timer = None
+    rsteps = min(args.steps, 10)
     if not args.no_roofline:
+        from spectre_vit import hip_ops
         if rank == 0:
             timer = hip_ops.KernelTimer()
             hip_ops.set_kernel_timer(timer)
-        for _ in range(min(args.steps, 20)):
-            step()
+            job.timer = timer
+        for _ in range(rsteps):
+            job.step()
         torch.cuda.synchronize()
         hip_ops.set_kernel_timer(None)
+        job.timer = None
     if world > 1:
         dist.barrier()
-    if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     final_loss = float(loss.item())
 
+    rec = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         total_images = args.batch * world * args.steps
@@ -217,22 +337,61 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if use_bf16 else "f32",
+            "dtype": "bf16" if job.use_bf16 else "f32",
             "data": "synthetic CIFAR-shaped randn images / randint labels resident in HBM, random-init weights (seed 42)",
-            "config": {"workload": (f"Spectre-ViT-Small (E512 H16 F768 L4 P4 N65, 100 classes, dropout 0.001), {args.mixer} mixer, "
+            "config": {"workload": "stand-in stock MLP on the CPU (launcher rehearsal only)" if stand_in else
+                                   (f"Spectre-ViT-Small (E512 H16 F768 L4 P4 N65, 100 classes, dropout 0.001), {args.mixer} mixer, "
                                     if args.model == "spectre" else
                                     "baseline ViT-Small (E512 H16 F768 L4 P4 N65, MHSA with the reference's batch_first=False axis), ")
                                    + f"train step fwd+CE+bwd+AdamW, bs {args.batch}/GPU",
-                       **({"rehearsal": "all ranks on one device over gloo: control-flow check, not a measurement"} if rehearsal else {}),
-                       "mixer": args.mixer if args.model == "spectre" else "attention", "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                       **({"rehearsal": ("launcher / collective control flow on the CPU with a stock stand-in model: not a measurement"
+                                         if stand_in else
+                                         "all ranks on one device over gloo: control-flow check, not a measurement")} if rehearsal else {}),
+                       "mixer": args.mixer if args.model == "spectre" else "attention", "global_batch": args.batch * world,
+                       "parallelism": f"dp{world}"},
+            "rccl_ranks": world if backend == "nccl" else 0,
+            "backend": backend or "none (single process)",
             "final_loss": round(final_loss, 4),
         }
         if timer is not None:
             rec["roofline"] = timer.roofline()
-            rec["kernels"] = timer.summary()
-            attach_pmc_traffic(rec["roofline"], args.mixer)
+            kern = timer.summary()
+            for d in kern:  # per-step figures
+                d["launches_per_step"] = round(d["launches"] / rsteps, 2)
+                d["ms_per_step"] = round(d.pop("total_ms") / rsteps, 4)
+                d.pop("launches")
+            rec["kernels"] = kern
+            covered = sum(d["ms_per_step"] for d in kern)
+            rec["kernels_coverage"] = {"bracketed_ms_per_step": round(covered, 3), "frac_of_step": round(covered / ms, 3),
+                                       "note": "sum of bracketed launch durations / clean ms_per_step; the rest is torch glue "
+                                               "(loss, casts, fills) and launch gaps"}
+            if rec["roofline"]:
+                rec["roofline"]["launches"] = round(rec["roofline"]["launches"] / rsteps, 2)
+                attach_pmc_traffic(rec["roofline"], args.mixer)
+
+    # other mixers of the same model, a few steps each (single GPU only: SURVEY 8d asks for the HEAD-default MHPermutMix
+    # and the DWT configuration next to the FFT headline)
+    variants = args.variants
+    if variants is None:
+        variants = "permut,dwt_embed" if (world == 1 and args.model == "spectre" and args.mixer == "fft" and not stand_in) else "none"
+    if variants != "none" and world == 1:
+        del job
+        torch.cuda.empty_cache()
+        out = {}
+        for mx in [v for v in variants.split(",") if v]:
+            vjob = Job(args, mx, dev, rank)
+            vsteps = max(5, min(args.steps, 20))
+            vel, vloss = timed_region(vjob, sync, vsteps, min(args.warmup, 5))
+            out[mx] = dict(value=round(args.batch * vsteps / vel, 1), unit="images/sec", ms_per_step=round(vel / vsteps * 1e3, 3),
+                           steps=vsteps, final_loss=round(float(vloss.item()), 4))
+            del vjob
+            torch.cuda.empty_cache()
+        rec["variants"] = out
+    if args.graph and world == 1 and not stand_in and args.model == "spectre":
+        rec["graph"] = graph_replay(args, args.mixer, dev, args.steps, args.warmup)
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"] = cpu_baseline(args.mixer)
+            rec["cpu_baseline"] = cpu_baseline(args.mixer, args.batch, args.cpu_steps)
         print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()

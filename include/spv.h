@@ -31,6 +31,20 @@ extern "C" {
 #define SPV_ABI_VERSION 1
 
 int spv_version(void);
+/* Dispatch census (test aid; no reference counterpart): how many calls each kernel family has served in this process, so a
+ * parity test can assert that the shapes it ran really took the fused / strip kernels the benchmark times. */
+enum {
+    SPV_PATH_GEMM_STRIP = 0,     /* gemm_nt_strip_kernel<*, false> */
+    SPV_PATH_GEMM_STRIP_ACC = 1, /* gemm_nt_strip_kernel<*, true>  */
+    SPV_PATH_GEMM_TN = 2,        /* weight-gradient kernel (spv_gemm_tn) */
+    SPV_PATH_TAIL_LC = 3,        /* lane-contiguous SpectreLinear tail kernels */
+    SPV_PATH_TAIL_UP = 4,        /* spv_spectre_tail_bwd_up */
+    SPV_PATH_TAIL_LN = 5,        /* spv_spectre_tail_ln_fwd / _bwd */
+    SPV_PATH_FNET_MFMA = 6,      /* fnet_mfma_kernel (bf16, dim 512) */
+    SPV_PATH_GATHER_LDS = 7,     /* LDS-staged MHPermutMix gather */
+    SPV_PATH_COUNT = 16
+};
+long long spv_path_count(int which);
 const char* spv_last_error(void);
 
 /* ---- precision plumbing -------------------------------------------------------------------
@@ -191,6 +205,15 @@ int spv_rfft_real(const void* x, void* y, int rows, int dim, int transpose, int 
  * element passes through.  inverse=1 applies the adjoint (= inverse = the backward). */
 int spv_haar_dwt(const void* x, void* y, int batch, int tokens, int dim, int axis, int levels, int inverse,
                  int dtype, void* scratch, void* stream);
+
+/* ---- Walsh-Hadamard butterflies along the last axis -----------------------------------
+ * spectre_vit/models/spectre/hadamar.py: fwht :12-32 / hadamard_transform :83-112 (mode 0, natural order; scale = n^-1/2
+ * when normalised), fwht_fast :58-80 (mode 1: every stage interleaves sum / difference, un-normalised) and its transpose
+ * (mode 2: the backward of mode 1; mode 0 is its own transpose).  LearnableHadamard.forward :127-141 is ONE call: rows of
+ * n_in values zero-padded to n (a power of two), `repeat` = num_blocks passes, the first n_out values kept, `residual`
+ * (nullable, [rows, n_out]) added.  x [rows, n_in], y [rows, n_out]; n <= 16384. */
+int spv_fwht(const void* x, void* y, const void* residual, int rows, int n_in, int n, int n_out, int mode, int repeat,
+             float scale, int dtype, void* stream);
 
 /* ---- patch embedding ---------------------------------------------------------------------------
  * tokens[b,0,:] = cls + pos[0]; tokens[b,1+n,:] = W_full . patch(b,n) + bias + pos[1+n]

@@ -86,14 +86,21 @@ def adaptive_pool_matrix(n_in, n_out, dtype=np.float64):
 # --------------------------------------------------------------------------------------
 # SpectreLinear  (layers.py:76-101)
 # --------------------------------------------------------------------------------------
+def _mm(x, M):
+    """x[..., k] @ M[k, n] through ONE 2-D BLAS call (numpy's batched matmul with a strided 2-D operand leaves BLAS and
+    ran the MHPermutMix linear 100x slower)."""
+    lead = x.shape[:-1]
+    return (x.reshape(-1, x.shape[-1]) @ M).reshape(*lead, M.shape[1])
+
+
 def spectre_linear_fwd(x, p):
     """out = GELU(LN(x W^T + b)) + avgpool(x)  -- layers.py:95-101.
     p: dict(weight (out,in), bias (out,), ln_weight, ln_bias)."""
     W = p["weight"]
-    h = x @ W.T + p["bias"]
+    h = _mm(x, W.T) + p["bias"]
     ln, ln_cache = layernorm_fwd(h, p["ln_weight"], p["ln_bias"])
     P = adaptive_pool_matrix(W.shape[1], W.shape[0], x.dtype)
-    out = gelu(ln) + x @ P.T
+    out = gelu(ln) + _mm(x, P.T)
     return out, (x, ln, ln_cache, P)
 
 
@@ -106,7 +113,7 @@ def spectre_linear_bwd(dout, p, cache):
     dh2 = dh.reshape(-1, W.shape[0])
     dW = dh2.T @ x.reshape(-1, K)
     db = dh2.sum(axis=0)
-    dx = dh @ W + dout @ P
+    dx = _mm(dh, W) + _mm(dout, P)
     return dx, dict(weight=dW, bias=db, ln_weight=dgamma, ln_bias=dbeta)
 
 
@@ -243,6 +250,75 @@ def haar_dwt_bwd(dy, axis=-1, levels=1):
         off += h
         da = haar_level_bwd(da, dd, -1)
     return np.moveaxis(da, -1, axis)
+
+
+# --------------------------------------------------------------------------------------
+# Walsh-Hadamard helpers  (hadamar.py:12-32, 58-80, 83-112, 115-141)
+# --------------------------------------------------------------------------------------
+def fwht(x, normalize=True):
+    """natural-order fast Walsh-Hadamard transform along the last axis -- hadamar.py:12-32 (== hadamard_transform :83-112
+    with normalize=True): stage h pairs (i, i+h) inside blocks of 2h."""
+    n = x.shape[-1]
+    y = x.reshape(-1, n).copy()
+    h = 1
+    while h < n:
+        v = y.reshape(-1, n // (2 * h), 2, h)
+        a, b = v[:, :, 0, :], v[:, :, 1, :]
+        y = np.concatenate((a + b, a - b), axis=2).reshape(-1, n)
+        h *= 2
+    y = y.reshape(x.shape)
+    return y * n ** -0.5 if normalize else y
+
+
+def fwht_fast_fwd(x):
+    """hadamar.py:58-80: per stage, block of 2h -> a = first h, b = last h, output interleaved (a+b)[i], (a-b)[i]."""
+    n = x.shape[-1]
+    y = x.reshape(-1, n).copy()
+    h = 1
+    while h < n:
+        v = y.reshape(y.shape[0], -1, 2 * h)
+        a, b = v[..., :h], v[..., h:]
+        out = np.empty_like(v)
+        out[..., 0::2] = a + b
+        out[..., 1::2] = a - b
+        y = out.reshape(-1, n)
+        h *= 2
+    return y.reshape(x.shape)
+
+
+def fwht_fast_bwd(dy):
+    """transpose of fwht_fast_fwd: stages in reverse order, each stage transposed."""
+    n = dy.shape[-1]
+    g = dy.reshape(-1, n).copy()
+    h = n // 2
+    while h >= 1:
+        v = g.reshape(g.shape[0], -1, 2 * h)
+        u, w = v[..., 0::2], v[..., 1::2]
+        out = np.empty_like(v)
+        out[..., :h] = u + w
+        out[..., h:] = u - w
+        g = out.reshape(-1, n)
+        h //= 2
+    return g.reshape(dy.shape)
+
+
+def learnable_hadamard_fwd(x, num_blocks):
+    """LearnableHadamard.forward -- hadamar.py:127-141 (parameters unused: `# * p` :136)."""
+    d = x.shape[-1]
+    n = 1 << (d - 1).bit_length()
+    y = np.concatenate([x, np.zeros(x.shape[:-1] + (n - d,), x.dtype)], axis=-1)
+    for _ in range(num_blocks):
+        y = fwht_fast_fwd(y)
+    return y[..., :d] + x
+
+
+def learnable_hadamard_bwd(dy, num_blocks):
+    d = dy.shape[-1]
+    n = 1 << (d - 1).bit_length()
+    g = np.concatenate([dy, np.zeros(dy.shape[:-1] + (n - d,), dy.dtype)], axis=-1)
+    for _ in range(num_blocks):
+        g = fwht_fast_bwd(g)
+    return g[..., :d] + dy
 
 
 # --------------------------------------------------------------------------------------

@@ -191,7 +191,64 @@ def model_fixture(name, cfg, batch, seed):
     print(f"{name}.npz:", len(d), "arrays, loss", float(loss))
 
 
+def config_fixtures():
+    """values of every reference config module as parse_config would return them (spectre_vit/configs/*.py; the reference's
+    parse_config itself needs Python 3.13 -- SimpleNamespace(mapping) -- so its two steps are applied by hand: module_to_dict,
+    then `mod |= base_mod` when the literal key __base__ is present, parser.py:22-25)."""
+    import importlib
+    import json
+    from spectre_vit.configs.parser import module_to_dict
+    out = {}
+    cfg_dir = os.path.join(REF, "spectre_vit", "configs")
+    for f in sorted(os.listdir(cfg_dir)):
+        if not f.endswith(".py") or f in ("parser.py", "__init__.py"):
+            continue
+        name = f[:-3]
+        mod = module_to_dict(importlib.import_module(f"spectre_vit.configs.{name}"))
+        if "__base__" in mod:
+            mod |= module_to_dict(importlib.import_module("spectre_vit.configs." + mod["__base__"].replace(".py", "")))
+        out[name] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in mod.items()}
+    json.dump(out, open(os.path.join(OUT, "configs.json"), "w"), indent=1, sort_keys=True)
+    print("configs.json:", sorted(out))
+
+
+def hadamard_fixtures():
+    """fwht (hadamar.py:12-32), fwht_fast (:58-80), hadamard_transform (:83-112), LearnableHadamard (:115-141)."""
+    from spectre_vit.models.spectre.hadamar import LearnableHadamard, fwht, fwht_fast, hadamard_transform
+    d = {}
+    for n in (2, 8, 64, 512):
+        x = torch.randn(3, 5, n, generator=gen(100 + n)).double().requires_grad_(True)
+        dy = torch.randn(3, 5, n, generator=gen(200 + n)).double()
+        for name, fn in (("fwht", lambda t: fwht(t)), ("fwht_raw", lambda t: fwht(t, normalize=False)), ("fwht_fast", fwht_fast)):
+            x.grad = None
+            y = fn(x)
+            y.backward(dy)
+            d.update({f"{name}.{n}.x": npy(x), f"{name}.{n}.y": npy(y), f"{name}.{n}.dy": npy(dy), f"{name}.{n}.dx": npy(x.grad)})
+        x2 = torch.randn(4, n, generator=gen(300 + n)).double()
+        d.update({f"hadamard_transform.{n}.x": npy(x2), f"hadamard_transform.{n}.y": npy(hadamard_transform(x2))})
+    # fwht along a non-last axis (token axis of a (B, N, D) tensor)
+    x = torch.randn(2, 16, 6, generator=gen(41)).double()
+    d.update({"fwht_dim1.x": npy(x), "fwht_dim1.y": npy(fwht(x, dim=1))})
+    for dim, blocks in ((48, 2), (64, 1), (100, 3)):
+        torch.manual_seed(7)
+        m = LearnableHadamard(dim, num_blocks=blocks).double()
+        x = torch.randn(2, 7, dim, generator=gen(400 + dim)).double().requires_grad_(True)
+        dy = torch.randn(2, 7, dim, generator=gen(500 + dim)).double()
+        y = m(x)
+        y.backward(dy)
+        key = f"lh.{dim}.{blocks}"
+        d.update({key + ".x": npy(x), key + ".y": npy(y), key + ".dy": npy(dy), key + ".dx": npy(x.grad)})
+        d[key + ".param_grads_none"] = np.array(all(p.grad is None for p in m.params))
+        d[key + ".state_keys"] = np.array(",".join(m.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, "hadamard.npz"), **d)
+    print("hadamard.npz:", len(d), "arrays")
+
+
 if __name__ == "__main__":
+    config_fixtures()
+    hadamard_fixtures()
+    if "--aux-only" in sys.argv:
+        sys.exit(0)
     op_fixtures()
     # Tiny/MNIST: configs/spectre_vit_mnist.py:3-19 (img 28, P 4, C 3, E 48, H 8, F 256, L 4, 100 classes)
     model_fixture("model_tiny_mnist", dict(img_size=28, patch_size=4, in_channels=3, num_classes=100,

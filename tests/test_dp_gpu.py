@@ -48,7 +48,7 @@ def _worker(rank, world, port, mixer, outdir):
     for _ in range(2):
         red.zero_grad()
         torch.nn.functional.cross_entropy(m(xs), ys).backward()
-        adopted = sum(int(p.grad.data_ptr() == p._spv_grad_sink.view.data_ptr()) for p in m.parameters())
+        adopted = red.adopted  # counted inside the reducer's hook BEFORE it re-points p.grad: kernels wrote into the slot and autograd kept it
         red.finish()
     torch.save(dict(grads={k: p.grad.detach().cpu().clone() for k, p in m.named_parameters()},
                     sd={k: v.cpu() for k, v in m.state_dict().items()}, adopted=adopted, nparams=len(list(m.parameters()))),
@@ -87,19 +87,41 @@ def test_two_ranks_on_one_gpu(mixer, tmp_path):
 
 @pytest.mark.gpu
 def test_bench_multi_rank_control_flow(tmp_path):
-    """bench.py with 2 ranks (both on device 0, gloo): every collective is entered by every rank -- in particular the
-    roofline pass after the timed region, whose steps contain the gradient all-reduce -- and rank 0 prints one JSON line."""
+    """`python bench.py --gpus 2` with NO external launcher (what the driver runs): bench.py spawns its own ranks; here both sit on
+    device 0 over gloo (SPV_BENCH_REHEARSAL=1) with the real model and kernels.  Every collective is entered by every rank -- in
+    particular the roofline pass after the timed region, whose steps contain the gradient all-reduce -- and rank 0 prints one JSON line."""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SPV_BENCH_REHEARSAL="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "64"]
-    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 128
-    assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec
+    assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec and rec["backend"] == "gloo"
+    assert rec["kernels_coverage"]["frac_of_step"] > 0.3
+
+
+@pytest.mark.gpu
+def test_bench_single_gpu_line_has_variants_and_cpu_baseline():
+    """the default single-GPU line: roofline of the dominant kernel, >= 90 % of the step bracketed, the HEAD-default MHPermutMix
+    and the DWT configuration under "variants", and the CPU baseline leg (short here: 1 step of bs 64)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SPV_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--batch", "64", "--cpu-steps", "1", "--graph"]
+    r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and set(rec["variants"]) == {"permut", "dwt_embed"}
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["value"] > 0
+    assert rec["roofline"]["bound"] in ("hbm", "mfma") and 0 < rec["roofline"]["frac"] < 1
+    assert rec["graph"]["graph_ms_per_step"] > 0

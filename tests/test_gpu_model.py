@@ -8,6 +8,22 @@ from conftest import load_model_fixture
 from oracle import spectre_oracle as O
 from test_gpu_ops import check, dev, n64, t
 
+
+def rel_l2(got, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.linalg.norm(n64(got) - ref) / (np.linalg.norm(ref) + 1e-300))
+
+
+def check_l2(got, ref, tol, what=""):
+    """per-tensor relative L2: every element counts (max|err| / max|ref| hides errors on small-magnitude entries)"""
+    e = rel_l2(got, ref)
+    assert e <= tol, f"{what}: rel-L2 {e:.3e} > {tol:.1e}"
+
+
+# whole-model bounds: fp32 kernels vs the float64 oracle in max-norm (tight); bf16 kernels (bf16 storage, fp32 accumulate) in
+# relative L2 per tensor
+BF16_L2 = 1.5e-2
+
 pytestmark = pytest.mark.gpu
 
 
@@ -63,7 +79,7 @@ def test_model_train_step_golden(name):
 @pytest.mark.parametrize("mixer,kw", [("fft", {}), ("dwt_embed", {"dwt_levels": 2}), ("dwt_token", {}), ("permut", {})])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_model_vs_oracle_mixers(mixer, kw, dtype):
-    """cut-down Small with every mixer; fp32 within 2e-4 of the float64 oracle, bf16 autocast within 6e-2."""
+    """cut-down Small with every mixer; fp32 within 2e-4 (max-norm) of the float64 oracle, bf16 autocast within 1.5e-2 relative L2 per tensor."""
     cfg = dict(img_size=16, patch_size=4, in_channels=3, num_classes=100, embed_dim=64, num_encoders=2, num_heads=4,
                hidden_dim=96, dropout=0.0, activation="gelu")
     torch.manual_seed(42)
@@ -87,11 +103,16 @@ def test_model_vs_oracle_mixers(mixer, kw, dtype):
     assert logits.dtype == torch.float32
     loss = torch.nn.CrossEntropyLoss()(logits, labels.to(dev()))
     loss.backward()
-    tol = 2e-4 if dtype == torch.float32 else 6e-2
-    check(logits, logits_ref, tol, "logits")
-    check(cls, cls_ref, tol, "cls")
-    for k, p in m.named_parameters():
-        check(p.grad, gref[k], tol * 3, "grad " + k)
+    if dtype == torch.float32:
+        check(logits, logits_ref, 2e-4, "logits")
+        check(cls, cls_ref, 2e-4, "cls")
+        for k, p in m.named_parameters():
+            check(p.grad, gref[k], 6e-4, "grad " + k)
+    else:
+        check_l2(logits, logits_ref, BF16_L2, "logits")
+        check_l2(cls, cls_ref, BF16_L2, "cls")
+        for k, p in m.named_parameters():
+            check_l2(p.grad, gref[k], BF16_L2, "grad " + k)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -116,11 +137,16 @@ def test_layer_at_small_widths_vs_oracle(dtype):
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
         logits, cls = m(img.to(dev()), return_features=True)
     torch.nn.CrossEntropyLoss()(logits, labels.to(dev())).backward()
-    tol = 2e-4 if dtype == torch.float32 else 6e-2
-    check(logits, logits_ref, tol, "logits")
-    check(cls, cls_ref, tol, "cls")
-    for k, p in m.named_parameters():
-        check(p.grad, gref[k], tol * 3, "grad " + k)
+    if dtype == torch.float32:
+        check(logits, logits_ref, 2e-4, "logits")
+        check(cls, cls_ref, 2e-4, "cls")
+        for k, p in m.named_parameters():
+            check(p.grad, gref[k], 6e-4, "grad " + k)
+    else:
+        check_l2(logits, logits_ref, BF16_L2, "logits")
+        check_l2(cls, cls_ref, BF16_L2, "cls")
+        for k, p in m.named_parameters():
+            check_l2(p.grad, gref[k], BF16_L2, "grad " + k)
 
 
 def small_cfg():

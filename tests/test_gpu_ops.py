@@ -615,3 +615,61 @@ def test_dropout_kernel(ops):
 def test_cpu_tensor_fails_loudly(ops):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.FNetMixFn.apply(torch.randn(2, 5, 16))
+
+
+# ------------------------------------------------------------------------------------------------ Hadamard helpers
+@pytest.fixture(scope="module")
+def golden_hadamard():
+    import os
+    from conftest import GOLDEN
+    return dict(np.load(os.path.join(GOLDEN, "hadamard.npz")))
+
+
+@pytest.mark.parametrize("n", [2, 8, 64, 512])
+def test_hadamard_helpers_golden(golden_hadamard, n):
+    """fwht / fwht_fast / hadamard_transform (reference hadamar.py:12-32, 58-80, 83-112) on the HIP butterfly kernel against the
+    reference's own outputs and gradients (fp32 kernels, float64 fixtures)."""
+    from spectre_vit.models.spectre import hadamar as H
+    g = golden_hadamard
+    for name, fn in (("fwht", H.fwht), ("fwht_raw", lambda v: H.fwht(v, normalize=False)), ("fwht_fast", H.fwht_fast)):
+        x = t(g[f"{name}.{n}.x"]).requires_grad_(True)
+        y = fn(x)
+        y.backward(t(g[f"{name}.{n}.dy"]))
+        check(y, g[f"{name}.{n}.y"], 2e-6, f"{name} n={n} y")
+        check(x.grad, g[f"{name}.{n}.dx"], 2e-6, f"{name} n={n} dx")
+    check(H.hadamard_transform(t(g[f"hadamard_transform.{n}.x"])), g[f"hadamard_transform.{n}.y"], 2e-6, "hadamard_transform")
+    check(H.hadamard_transform(t(g[f"hadamard_transform.{n}.x"][0])), g[f"hadamard_transform.{n}.y"][0], 2e-6, "hadamard_transform 1-D")
+
+
+def test_fwht_other_axis_and_errors(golden_hadamard):
+    from spectre_vit.models.spectre import hadamar as H
+    g = golden_hadamard
+    check(H.fwht(t(g["fwht_dim1.x"]), dim=1), g["fwht_dim1.y"], 2e-6, "fwht dim=1")
+    with pytest.raises(ValueError):
+        H.fwht_fast(torch.zeros(2, 12, device=dev()))
+    with pytest.raises(AssertionError):
+        H.hadamard_transform(torch.zeros(2, 2, 8, device=dev()))
+    assert H.next_pow2(100) == 128 and H.next_pow2(64) == 64
+
+
+@pytest.mark.parametrize("dim,blocks", [(48, 2), (64, 1), (100, 3)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_learnable_hadamard_golden(golden_hadamard, dim, blocks, dtype):
+    """LearnableHadamard (hadamar.py:115-141): pad / num_blocks x fwht_fast / crop / + residual as one kernel; same state_dict keys;
+    the parameters take no part in the forward and get no gradient, as in the reference."""
+    from spectre_vit.models.spectre.hadamar import LearnableHadamard
+    g = golden_hadamard
+    key = f"lh.{dim}.{blocks}"
+    m = LearnableHadamard(dim, num_blocks=blocks).to(dev())
+    assert ",".join(m.state_dict().keys()) == str(g[key + ".state_keys"])
+    xq, dyq = q(g[key + ".x"], dtype), q(g[key + ".dy"], dtype)
+    x = t(xq, dtype).requires_grad_(True)
+    y = m(x)
+    y.backward(t(dyq, dtype))
+    tol = 2e-6 if dtype == torch.float32 else 8e-3  # bf16: output rounding only (fp32 butterflies in LDS)
+    check(y, O.learnable_hadamard_fwd(xq, blocks), tol, "y")
+    check(x.grad, O.learnable_hadamard_bwd(dyq, blocks), tol, "dx")
+    if dtype == torch.float32:
+        check(y, g[key + ".y"], 2e-6, "y vs reference")
+        check(x.grad, g[key + ".dx"], 2e-6, "dx vs reference")
+    assert all(p.grad is None for p in m.params)

@@ -234,3 +234,76 @@ def test_distill_loss_gradient_numeric():
         sm = s.copy(); sm[i] -= 1e-6
         num[i] = (O.distill_loss_fwd_bwd(sp, t, lab)[0] - O.distill_loss_fwd_bwd(sm, t, lab)[0]) / 2e-6
     close(d, num, rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("name", ["model_tiny_mnist", "model_small_cut"])
+def test_torch_cpu_port_train_step(name):
+    """bench.py's cpu_baseline leg (oracle/spectre_torch_cpu.py: stock ATen ops + autograd + torch AdamW) against the
+    reference's own logits / loss / gradients / post-AdamW weights."""
+    import torch
+    from oracle import spectre_torch_cpu as T
+    d, cfg = load_model_fixture(name)
+    sd = {k[3:]: v for k, v in d.items() if k.startswith("sd.")}
+    st = T.TrainState(sd, dtype=torch.float64)
+    grads = {}
+    img, labels = torch.as_tensor(d["img"], dtype=torch.float64), torch.as_tensor(d["labels"]).long()
+    logits, cls = T.forward(img, st.sd, cfg["num_encoders"], cfg["patch_size"], "permut")
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    close(logits.detach().numpy(), d["logits"], rtol=1e-8, atol=1e-9)
+    close(cls.detach().numpy(), d["cls"], rtol=1e-8, atol=1e-9)
+    close(loss.item(), d["loss"], rtol=1e-9)
+    n = 0
+    for k, v in d.items():
+        if k.startswith("grad."):
+            close(st.sd[k[5:]].grad.numpy(), v, rtol=1e-7, atol=1e-9)
+            n += 1
+    assert n == len(st.params)
+    st.step(img, labels, cfg["num_encoders"], cfg["patch_size"], "permut")
+    for k, v in d.items():
+        if k.startswith("after."):
+            close(st.sd[k[6:]].detach().numpy(), v, rtol=1e-7, atol=1e-9)
+
+
+def test_torch_cpu_port_fft_mixer_matches_numpy_oracle():
+    import torch
+    from oracle import spectre_torch_cpu as T
+    d, cfg = load_model_fixture("model_small_cut")
+    sd = {k[3:]: v for k, v in d.items() if k.startswith("sd.") and "mix_layer" not in k}
+    loss, logits, cls, grads = O.train_step(d["img"], d["labels"], sd, cfg["num_encoders"], cfg["patch_size"], "fft", np.float64)
+    st = T.TrainState(sd, dtype=torch.float64)
+    lg, _ = T.forward(torch.as_tensor(d["img"], dtype=torch.float64), st.sd, cfg["num_encoders"], cfg["patch_size"], "fft")
+    torch.nn.functional.cross_entropy(lg, torch.as_tensor(d["labels"]).long()).backward()
+    close(lg.detach().numpy(), logits, rtol=1e-8, atol=1e-9)
+    for k, gk in grads.items():
+        close(st.sd[k].grad.numpy(), gk, rtol=1e-6, atol=1e-9)
+
+
+@pytest.fixture(scope="module")
+def golden_hadamard():
+    import os
+    from conftest import GOLDEN
+    return dict(np.load(os.path.join(GOLDEN, "hadamard.npz")))
+
+
+@pytest.mark.parametrize("n", [2, 8, 64, 512])
+def test_hadamard_helpers(golden_hadamard, n):
+    """fwht / fwht_fast / hadamard_transform of reference hadamar.py, forward and backward."""
+    g = golden_hadamard
+    close(O.fwht(g[f"fwht.{n}.x"]), g[f"fwht.{n}.y"])
+    close(O.fwht(g[f"fwht.{n}.dy"]), g[f"fwht.{n}.dx"])  # symmetric matrix: backward == forward
+    close(O.fwht(g[f"fwht_raw.{n}.x"], normalize=False), g[f"fwht_raw.{n}.y"])
+    close(O.fwht(g[f"hadamard_transform.{n}.x"]), g[f"hadamard_transform.{n}.y"])
+    close(O.fwht_fast_fwd(g[f"fwht_fast.{n}.x"]), g[f"fwht_fast.{n}.y"])
+    close(O.fwht_fast_bwd(g[f"fwht_fast.{n}.dy"]), g[f"fwht_fast.{n}.dx"])
+    if n >= 8:  # SURVEY section 2 row 6 probe: fwht_fast is NOT fwht * sqrt(n) (different output ordering)
+        assert np.abs(O.fwht_fast_fwd(g[f"fwht.{n}.x"]) - g[f"fwht.{n}.y"] * np.sqrt(n)).max() > 1e-3
+
+
+@pytest.mark.parametrize("dim,blocks", [(48, 2), (64, 1), (100, 3)])
+def test_learnable_hadamard(golden_hadamard, dim, blocks):
+    g = golden_hadamard
+    key = f"lh.{dim}.{blocks}"
+    close(O.learnable_hadamard_fwd(g[key + ".x"], blocks), g[key + ".y"])
+    close(O.learnable_hadamard_bwd(g[key + ".dy"], blocks), g[key + ".dx"])
+    assert bool(g[key + ".param_grads_none"])

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_pass(counter, outdir, mixer):
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--mixer", mixer]
+           os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--variants", "none", "--mixer", mixer]
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     f = glob.glob(os.path.join(outdir, "*", "*counter_collection.csv"))[0]
@@ -30,7 +30,11 @@ def run_pass(counter, outdir, mixer):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
             agg[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
-    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+    dur = collections.defaultdict(list)
+    for t in glob.glob(os.path.join(outdir, "*", "*kernel_trace.csv")):
+        for r in csv.DictReader(open(t)):
+            dur[(r["Kernel_Name"], int(r["Grid_Size"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
+    return {k: (sum(v) / len(v), len(v), (sum(dur[k]) / len(dur[k]) if dur.get(k) else None)) for k, v in agg.items()}
 
 
 def main():
@@ -40,13 +44,13 @@ def main():
     fetch = run_pass("FETCH_SIZE", scratch + "_fetch", mixer)
     write = run_pass("WRITE_SIZE", scratch + "_write", mixer)
     out = []
-    for key in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 0))[0] + write.get(k, (0, 0))[0])):
+    for key in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, (0, 0, 0))[0] + write.get(k, (0, 0, 0))[0])):
         name, grid = key
-        f_kib, n = fetch.get(key, (0.0, 0))
-        w_kib, _ = write.get(key, (0.0, 0))
+        f_kib, n, us = fetch.get(key, (0.0, 0, None))
+        w_kib, _, _ = write.get(key, (0.0, 0, None))
         short = name.replace("void ", "").replace("(anonymous namespace)::", "")
         short = short.split("(")[0].strip()[:90]
-        out.append(dict(kernel=short, grid_size=grid, launches=n, fetch_size_kib=round(f_kib, 1), write_size_kib=round(w_kib, 1),
+        out.append(dict(kernel=short, grid_size=grid, launches=n, avg_us=None if us is None else round(us, 2), fetch_size_kib=round(f_kib, 1), write_size_kib=round(w_kib, 1),
                         fetch_bytes_x2=int(f_kib * 1024 * 2), write_bytes=int(w_kib * 1024),
                         hbm_bytes_corrected=int(f_kib * 1024 * 2 + w_kib * 1024)))
     path = os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_traffic.json")

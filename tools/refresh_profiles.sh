@@ -9,11 +9,11 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 for MIX in fft permut dwt_embed; do
-  echo "== bench $MIX"; python3 "$ROOT/bench.py" --mixer $MIX > "$OUT/${TAG}_${MIX}_bs512_bench.json" 2> "$OUT/${MIX}_bench.err" || echo "bench $MIX failed"
+  echo "== bench $MIX"; python3 "$ROOT/bench.py" --mixer $MIX --variants none > "$OUT/${TAG}_${MIX}_bs512_bench.json" 2> "$OUT/${MIX}_bench.err" || echo "bench $MIX failed"
   tail -c 300 "$OUT/${TAG}_${MIX}_bs512_bench.json" | head -c 10 > /dev/null
   echo "== stats $MIX"
   rm -rf /tmp/prof_$MIX
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$MIX -o p -- python3 "$ROOT/bench.py" --mixer $MIX --steps 20 --warmup 5 --no-roofline --no-cpu-baseline > "$OUT/${MIX}_stats.log" 2>&1 || echo "stats $MIX failed"
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$MIX -o p -- python3 "$ROOT/bench.py" --mixer $MIX --steps 20 --warmup 5 --no-roofline --no-cpu-baseline --variants none > "$OUT/${MIX}_stats.log" 2>&1 || echo "stats $MIX failed"
   F=$(find /tmp/prof_$MIX -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && cp "$F" "$OUT/${TAG}_${MIX}_bs512_kernel_stats.csv"
 done

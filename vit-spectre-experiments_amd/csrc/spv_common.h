@@ -24,6 +24,9 @@ int spv_set_error(const char* fmt, ...);
         if (e_ != hipSuccess) return spv_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
     } while (0)
 
+extern long long g_spv_path_counts[SPV_PATH_COUNT];
+#define SPV_COUNT_PATH(which) (++g_spv_path_counts[which])
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- bf16 <-> f32 (device)

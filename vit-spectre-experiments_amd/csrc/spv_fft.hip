@@ -733,7 +733,8 @@ extern "C" int spv_fnet_mix(const void* x, void* y, const void* add_in, const fl
         const int rows = std::max(2 * ((tokens + 1) / 2), 2 * (tokens / 2 + 1));
         const size_t lds = (size_t)rows * V2RS;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(fnet_mfma_kernel<0>, dim3(batch), dim3(512), lds, st, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y),
+        SPV_COUNT_PATH(SPV_PATH_FNET_MFMA);
+    hipLaunchKernelGGL(fnet_mfma_kernel<0>, dim3(batch), dim3(512), lds, st, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y),
                            reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)), twiddle + v2_extra_off(tokens),
                            twiddle + v2_tw_off(tokens), tokens, v2_stagger, static_cast<const bf16_t*>(add_in), FnetLn{});
         SPV_LAUNCH_CHECK("spv_fnet_mix(v2)");
@@ -824,6 +825,7 @@ extern "C" int spv_fnet_ln_fwd(const void* x, void* prenorm, void* out, const fl
     hipStream_t st = static_cast<hipStream_t>(stream);
     FnetLn ln{gamma, beta, mean, rstd, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(prenorm), nullptr, nullptr};
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    SPV_COUNT_PATH(SPV_PATH_FNET_MFMA);
     hipLaunchKernelGGL(fnet_mfma_kernel<1>, dim3(batch), dim3(512), fnet_v2_lds(tokens), st, static_cast<const bf16_t*>(x),
                        static_cast<bf16_t*>(out), reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)), twiddle + v2_extra_off(tokens),
                        twiddle + v2_tw_off(tokens), tokens, 0, static_cast<const bf16_t*>(nullptr), ln);
@@ -841,6 +843,7 @@ extern "C" int spv_fnet_ln_bwd(const void* dout, const void* prenorm, const floa
     FnetLn ln{gamma, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), nullptr, nullptr, static_cast<const bf16_t*>(prenorm), partials};
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // input = dout (LayerNorm backward applied while it is staged); + dout again at the end: the residual path
+    SPV_COUNT_PATH(SPV_PATH_FNET_MFMA);
     hipLaunchKernelGGL(fnet_mfma_kernel<2>, dim3(batch), dim3(512), fnet_v2_lds(tokens) + 2 * V2D * sizeof(float), st,
                        static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dx), reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)),
                        twiddle + v2_extra_off(tokens), twiddle + v2_tw_off(tokens), tokens, 0, static_cast<const bf16_t*>(dout), ln);

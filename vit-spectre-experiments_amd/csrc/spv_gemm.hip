@@ -969,6 +969,7 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
                        static_cast<const bf16_t*>(B), bias, static_cast<bf16_t*>(C), M, K, lda, ldb, ldc, nstrips, base, rem, nwg)
             static const int acc_mb = getenv("SPV_STRIP_ACC_MB") ? atoi(getenv("SPV_STRIP_ACC_MB")) : 0;  // tuning aid
             if (accumulate && acc_mb >= 2 && acc_mb <= 4) mb = acc_mb;
+            SPV_COUNT_PATH(accumulate ? SPV_PATH_GEMM_STRIP_ACC : SPV_PATH_GEMM_STRIP);
             if (accumulate) {
                 if (mb == 4) SPV_STRIP(4, true);
                 else if (mb == 3) SPV_STRIP(3, true);
@@ -1080,6 +1081,7 @@ static int gemm_entry(const void* A, const void* B, const float* bias, void* C, 
 
 extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
                            int accumulate, int splits, void* workspace, void* stream) {
+    SPV_COUNT_PATH(SPV_PATH_GEMM_TN);
     SPV_CHECK(M > 0 && N > 0 && K > 0, "spv_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
     SPV_CHECK(out_dtype == SPV_F32 || out_dtype == SPV_BF16, "spv_gemm_tn: bad out_dtype %d", out_dtype);
     SPV_CHECK(M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0,

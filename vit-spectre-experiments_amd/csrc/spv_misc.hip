@@ -13,6 +13,12 @@ int spv_set_error(const char* fmt, ...) {
     return 1;
 }
 
+// dispatch census (test aid): which kernel family served a call -- spv_path_count(SPV_PATH_*)
+long long g_spv_path_counts[SPV_PATH_COUNT] = {0};
+extern "C" long long spv_path_count(int which) {
+    return (which >= 0 && which < SPV_PATH_COUNT) ? g_spv_path_counts[which] : -1;
+}
+
 extern "C" int spv_version(void) { return SPV_ABI_VERSION; }
 extern "C" const char* spv_last_error(void) { return g_err; }
 

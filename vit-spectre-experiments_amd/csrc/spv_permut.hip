@@ -205,6 +205,7 @@ extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g
         const size_t lds = (size_t)d * es;
         if (dtype == SPV_BF16) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+            SPV_COUNT_PATH(SPV_PATH_GATHER_LDS);
             hipLaunchKernelGGL((gather_fwd_lds_kernel<bf16_t>), dim3(batch), dim3(PT), lds, st, (const bf16_t*)x, idx, (bf16_t*)g, heads, d, (bf16_t*)pooled, pool_window);
         } else {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);

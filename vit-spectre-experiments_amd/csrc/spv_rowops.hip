@@ -919,6 +919,7 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
         dim3 lgrid(std::min(cdiv(rows, RW), 2048));
 #define LC_FWD(CO, CI)                                                                                                        \
         if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
+            SPV_COUNT_PATH(SPV_PATH_TAIL_LC); \
             if (fast) hipLaunchKernelGGL((tail_fwd_lc_kernel<CO, CI, true, false>), lgrid, dim3(RT), 0, static_cast<hipStream_t>(stream), h, x, gamma, beta, out, mean, rstd, rows, bfl, obf, p_drop, seed, TailLn2{}); \
             else hipLaunchKernelGGL((tail_fwd_lc_kernel<CO, CI, false, false>), lgrid, dim3(RT), 0, static_cast<hipStream_t>(stream), h, x, gamma, beta, out, mean, rstd, rows, bfl, obf, p_drop, seed, TailLn2{});    \
             SPV_LAUNCH_CHECK("spv_spectre_tail_fwd(lc)");                                                                     \
@@ -955,6 +956,7 @@ static int tail_bwd_impl(const void* dout, const void* h, const float* mean, con
 #define LC_BWD(CO, CI)                                                                                                        \
         if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
             hipStream_t lst = static_cast<hipStream_t>(stream);                                                               \
+            SPV_COUNT_PATH(up.src ? SPV_PATH_TAIL_UP : SPV_PATH_TAIL_LC); \
             if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{}, up); \
             else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{}, up);    \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc)");                                                                     \
@@ -1019,6 +1021,7 @@ extern "C" int spv_spectre_tail_ln_fwd(const void* h, const void* x, const float
     TailLn2 ln{res, gamma2, beta2, out2, mean2, rstd2, nullptr, nullptr, nullptr};
     dim3 lgrid(std::min(cdiv(rows, RW), 2048));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    SPV_COUNT_PATH(SPV_PATH_TAIL_LN);
     if (bfl) hipLaunchKernelGGL((tail_fwd_lc_kernel<8, 12, true, true>), lgrid, dim3(RT), 0, st, h, x, gamma, beta, out, mean, rstd, rows, bfl, bfl, p_drop, seed, ln);
     else hipLaunchKernelGGL((tail_fwd_lc_kernel<8, 12, false, true>), lgrid, dim3(RT), 0, st, h, x, gamma, beta, out, mean, rstd, rows, bfl, bfl, p_drop, seed, ln);
     SPV_LAUNCH_CHECK("spv_spectre_tail_ln_fwd");
@@ -1039,6 +1042,7 @@ extern "C" int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const 
     const int lwgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
     const size_t lds = (size_t)RW * 5 * n * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    SPV_COUNT_PATH(SPV_PATH_TAIL_LN);
     if (bfl) hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, true, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln, TailUp{nullptr, 0.0f, 0});
     else hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, false, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln, TailUp{nullptr, 0.0f, 0});
     SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd");

@@ -17,10 +17,14 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libspv_hip.so")
 
 c_vp, c_i, c_i64, c_u64, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
+# indices of include/spv.h's SPV_PATH_* enum (dispatch census, test aid)
+PATH = dict(gemm_strip=0, gemm_strip_acc=1, gemm_tn=2, tail_lc=3, tail_up=4, tail_ln=5, fnet_mfma=6, gather_lds=7)
+
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/spv.h one to one
 SIGNATURES = {
     "spv_version": [],
     "spv_last_error": [],
+    "spv_path_count": [c_i],
     "spv_cast": [c_vp, c_i, c_vp, c_i, c_i64, c_vp],
     "spv_cast_transpose": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_weight_shadows": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
@@ -65,13 +69,18 @@ SIGNATURES = {
     "spv_gelu_fwd": [c_vp, c_vp, c_i64, c_i, c_vp],
     "spv_gelu_bwd": [c_vp, c_vp, c_vp, c_i64, c_i, c_vp],
     "spv_colsum": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "spv_fwht": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_vp],
     "spv_axpby": [c_vp, c_vp, c_vp, c_f, c_f, c_i64, c_i, c_vp],
 }
-_RESTYPES = {"spv_last_error": ctypes.c_char_p, "spv_rowop_partial_floats": c_i64, "spv_fnet_workspace_floats": c_i64,
+_RESTYPES = {"spv_last_error": ctypes.c_char_p, "spv_path_count": ctypes.c_longlong, "spv_rowop_partial_floats": c_i64, "spv_fnet_workspace_floats": c_i64,
              "spv_fnet_twiddle_floats": c_i64, "spv_tail_ln_partial_floats": c_i64}
 _NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_tail_ln_supported", "spv_tail_up_supported"}
 
 _lib = None
+# live kernel timing (bench.py's roofline pass): when set, every entry point that launches on a stream is bracketed with HIP
+# events by ``timer.bracket(name, ints, launch)``; ints = the integer arguments (shapes, dtype codes, flags) in header order
+timer = None
+_LAUNCHERS = {}
 
 
 def load():
@@ -87,6 +96,8 @@ def load():
             fn = getattr(lib, name)  # AttributeError here == header/library mismatch
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_i)
+            if argtypes and argtypes[-1] is c_vp and name not in _NO_STATUS and name != "spv_fnet_make_twiddle":
+                _LAUNCHERS[name] = [i for i, t in enumerate(argtypes) if t in (c_i, c_i64)]
         if lib.spv_version() != 1:
             raise RuntimeError(f"libspv_hip.so ABI version {lib.spv_version()} != 1")
         _lib = lib
@@ -96,7 +107,13 @@ def load():
 def call(name, *args):
     """Invoke a status-returning entry point; raise RuntimeError(spv_last_error()) on failure."""
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if timer is not None and name in _LAUNCHERS:
+        ints = tuple(int(args[i]) for i in _LAUNCHERS[name])
+        box = []
+        timer.bracket(name, ints, lambda: box.append(getattr(lib, name)(*args)))
+        rc = box[0]
+    else:
+        rc = getattr(lib, name)(*args)
     if name in _NO_STATUS:
         return rc
     if rc != 0:

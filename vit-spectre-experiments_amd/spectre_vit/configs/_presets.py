@@ -23,10 +23,13 @@ PRESETS = {
     "spectre_vit_cifar100": dict(_common(32, 512, 16, 768), __base__="default.py"),
     # reference configs/spectre_vit_mnist.py:3-19 (embed_dim = patch_size**2 * in_channels = 48)
     "spectre_vit_mnist": dict(_common(28, 48, 8, 256), _base_=["./default.py"]),
-    # reference configs/vit_cifar100.py, fnet_cifar100.py, spectre_branch.py: same Small/CIFAR values
+    # reference configs/vit_cifar100.py, fnet_cifar100.py: same Small/CIFAR values
     "vit_cifar100": dict(_common(32, 512, 16, 768), _base_=["./default.py"]),
     "fnet_cifar100": dict(_common(32, 512, 16, 768), _base_=["./default.py"]),
-    "spectre_branch": dict(_common(32, 512, 16, 768), _base_=["./default.py"]),
+    # reference configs/spectre_branch.py:1-23: its own values (bs 512, 5000 epochs, 8 heads, hidden 256, embed 768), `_base_` a
+    # plain string, and NO val_batch_size
+    "spectre_branch": {k: v for k, v in dict(_common(32, 768, 8, 256), batch_size=512, epochs=5000, _base_="default.py").items()
+                       if k != "val_batch_size"},
     # reference configs/vit_mnist.py, fnet_mnist.py: Small on 28 x 28
     "vit_mnist": dict(_common(28, 512, 16, 768), _base_=["./default.py"]),
     "fnet_mnist": dict(_common(28, 512, 16, 768), _base_=["./default.py"]),

@@ -61,12 +61,15 @@ class SyntheticCifar:
         self.mean = torch.tensor(CIFAR_MEAN[:c.in_channels], device=device).view(1, -1, 1, 1)
         self.std = torch.tensor(CIFAR_STD[:c.in_channels], device=device).view(1, -1, 1, 1)
 
-    def batches(self, batch_size, shuffle, generator=None, rank=0, world=1, raw_uint8=False):
-        """raw_uint8: yield the uint8 NHWC batch itself; the model's patch gather normalises it."""
+    def batches(self, batch_size, shuffle, generator=None, rank=0, world=1, raw_uint8=False, drop_last=True):
+        """raw_uint8: yield the uint8 NHWC batch itself; the model's patch gather normalises it.
+        drop_last=False (validation): the short tail batch is yielded too, so every sample of the rank's shard is seen
+        (the reference's DataLoader default, train.py:151-155)."""
         n = self.images.shape[0]
         idx = torch.randperm(n, generator=generator) if shuffle else torch.arange(n)
         idx = idx[rank::world].to(self.images.device)
-        for i in range(0, idx.numel() - batch_size + 1, batch_size):
+        stop = idx.numel() - batch_size + 1 if drop_last else idx.numel()
+        for i in range(0, stop, batch_size):
             sel = idx[i:i + batch_size]
             if raw_uint8:
                 yield self.images[sel].permute(0, 2, 3, 1).contiguous(), self.labels[sel]
@@ -83,9 +86,9 @@ def train(config_path, mixer="permut", epochs=1, steps_per_epoch=None, batch_siz
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)  # always: kernels launch on the current device's stream (also with a pre-initialised group)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")
     device = torch.device("cuda", local_rank)
     seed_everything(seed)
@@ -138,20 +141,21 @@ def train(config_path, mixer="permut", epochs=1, steps_per_epoch=None, batch_siz
         v_loss = torch.zeros((), device=device)
         v_total, v_steps = 0, 0
         with torch.no_grad():
-            for img, label in val_set.batches(min(c.val_batch_size, n_val), False, None, rank, world, raw_uint8=uint8_input and not distill):
+            for img, label in val_set.batches(min(getattr(c, "val_batch_size", batch_size), n_val), False, None, rank, world,
+                                              raw_uint8=uint8_input and not distill, drop_last=False):
                 with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp and not distill):
                     y_pred = model(img)
                 v_correct += (label == torch.argmax(y_pred, dim=1)).sum()
-                v_loss += criterion(y_pred, label.long())
+                v_loss += criterion(y_pred, label.long()) * label.size(0)  # sample-weighted: the tail batch is short
                 v_total += label.size(0)
                 v_steps += 1
-        stats = torch.stack([v_correct.float(), torch.tensor(float(v_total), device=device), v_loss, torch.tensor(float(v_steps), device=device)])
+        stats = torch.stack([v_correct.float(), torch.tensor(float(v_total), device=device), v_loss])
         if world > 1:
             dist.all_reduce(stats)
         val_acc = (stats[0] / stats[1].clamp(min=1)).item()
-        val_loss = (stats[2] / stats[3].clamp(min=1)).item()
+        val_loss = (stats[2] / stats[1].clamp(min=1)).item()
         rec = {"epoch": epoch + 1, "Loss/Train": train_loss, "Loss/Validation": val_loss, "Accuracy/Train": train_acc,
-               "Accuracy/Validation": val_acc, "steps": steps}
+               "Accuracy/Validation": val_acc, "steps": steps, "val_samples": int(stats[1].item())}
         history.append(rec)
         if rank == 0:
             log_f.write(json.dumps(rec) + "\n")

@@ -34,10 +34,17 @@ def _dt(t):
 
 
 def _require_gpu(*tensors):
+    """every tensor on a HIP device, and on the CURRENT one: kernels are launched on torch.cuda.current_stream(), which belongs
+    to the current device -- raw pointers of another GPU on that stream would fault or run unordered."""
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("Spectre-ViT HIP kernels need tensors on an AMD GPU (cuda/HIP device); "
                                "there is no CPU fallback in this package")
+        if t.device.index != torch.cuda.current_device():
+            raise RuntimeError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: call "
+                               "torch.cuda.set_device(local_rank) (or use `with torch.cuda.device(...)`) before the model runs")
 
 
 _warned_fp16 = False
@@ -138,27 +145,58 @@ _register_post_step(invalidate_weight_shadows)  # any torch optimizer's step() i
 
 
 # ------------------------------------------------------------------------------------------------
-# live kernel timing for bench.py's roofline block: HIP events recorded on the launch stream around every call of
-# the selected C-ABI entry points (torch.cuda.Event records on torch's current stream == the stream we launch on)
+# live kernel timing for bench.py's roofline block: HIP events recorded on the launch stream around EVERY C-ABI entry
+# point that launches (hooked in _native.call; torch.cuda.Event records on torch's current stream == the stream we launch on)
 # ------------------------------------------------------------------------------------------------
 PEAK_TFLOPS = {BF16: 2500.0, F32: 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
+def _es(dt):
+    return 2 if dt == BF16 else 4
+
+
+# entry point -> f(ints) -> (label, shape, dtype code, bound, algorithmic work per call: flops (mfma) or compulsory bytes (hbm)).
+# ints are the integer arguments of the C-ABI call in header order (include/spv.h).
+_WORK_MODELS = {
+    "spv_gemm_nt": lambda i: ("gemm", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
+    "spv_gemm_nt_grouped_rows": lambda i: ("gemm_grouped_rows", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
+    "spv_gemm_nt_pool_bwd": lambda i: ("gemm_pool_bwd", i[1:4], i[7], "mfma", 2.0 * i[1] * i[2] * i[3]),
+    "spv_gemm_tn": lambda i: ("gemm_tn", i[0:3], BF16, "mfma", 2.0 * i[0] * i[1] * i[2]),
+    # read h [rows,n] + x [rows,k], write out [rows,n]
+    "spv_spectre_tail_fwd": lambda i: ("tail_fwd", i[0:3], i[3], "hbm", i[0] * (2.0 * i[1] + i[2]) * _es(i[3])),
+    # read dout, h; write dh [rows,n] and dx_pool [rows,k]
+    "spv_spectre_tail_bwd": lambda i: ("tail_bwd", i[0:3], i[3], "hbm", i[0] * (3.0 * i[1] + i[2]) * _es(i[3])),
+    # + read dx_add and up_src [rows,k]
+    "spv_spectre_tail_bwd_up": lambda i: ("tail_bwd_up", i[0:3], i[3], "hbm", i[0] * (3.0 * i[1] + 3.0 * i[2]) * _es(i[3])),
+    # read h3, res [rows,n], x [rows,k]; write f3, out2 [rows,n]
+    "spv_spectre_tail_ln_fwd": lambda i: ("tail_ln_fwd", i[0:3], i[3], "hbm", i[0] * (4.0 * i[1] + i[2]) * _es(i[3])),
+    # read dout2, f3, res, h3; write ds, dh3 [rows,n]
+    "spv_spectre_tail_ln_bwd": lambda i: ("tail_ln_bwd", i[0:3], i[3], "hbm", i[0] * 6.0 * i[1] * _es(i[3])),
+    "spv_add_layernorm_fwd": lambda i: ("addln_fwd", i[0:2], i[3], "hbm", 3.0 * i[0] * i[1] * _es(i[3])),
+    "spv_add_layernorm_bwd": lambda i: ("addln_bwd", i[0:2], i[3], "hbm", (3.0 + (i[2] == 1)) * i[0] * i[1] * _es(i[3])),
+    "spv_permut_gather_fwd": lambda i: ("gather_fwd", i[1:4], i[4], "hbm", i[1] * i[3] * (1.0 + i[2]) * _es(i[4])),
+    "spv_permut_gather_bwd": lambda i: ("gather_bwd", i[0:3], i[3], "hbm", i[0] * i[2] * (1.0 + i[1]) * _es(i[3])),
+    "spv_fnet_mix": lambda i: ("fnet_mix", i[0:3], i[3], "hbm", 2.0 * i[0] * i[1] * i[2] * _es(i[3])),
+    # mixer + LayerNorm-1 + residual: read x, write the pre-norm tensor and x1
+    "spv_fnet_ln_fwd": lambda i: ("fnet_ln_fwd", i[0:3], i[3], "hbm", 3.0 * i[0] * i[1] * i[2] * _es(i[3])),
+    # read dout and the pre-norm tensor, write dx
+    "spv_fnet_ln_bwd": lambda i: ("fnet_ln_bwd", i[0:3], i[3], "hbm", 3.0 * i[0] * i[1] * i[2] * _es(i[3])),
+    "spv_haar_dwt": lambda i: ("haar_dwt", i[0:3], i[6], "hbm", 2.0 * i[0] * i[1] * i[2] * _es(i[6])),
+    "spv_weight_shadows": lambda i: ("weight_shadows", i[0:2], i[3], "hbm", i[0] * i[1] * (4.0 + 2 * _es(i[3]))),
+    "spv_dropout": lambda i: ("dropout", i[0:1], i[1], "hbm", 2.0 * i[0] * _es(i[1])),
+    "spv_axpby": lambda i: ("axpby", i[0:1], i[1], "hbm", 3.0 * i[0] * _es(i[1])),
+    "spv_colsum": lambda i: ("colsum", i[0:2], i[2], "hbm", 1.0 * i[0] * i[1] * _es(i[2])),
+    "spv_cast": lambda i: ("cast", i[2:3], i[1], "hbm", 1.0 * i[2] * (_es(i[0]) + _es(i[1]))),
+}
+
+
 class KernelTimer:
     def __init__(self):
         self.records = []  # (name, key, start, end)
-        # cost of an empty event pair on this stream: subtracted from every bracket (a bracket otherwise reads ~4-5 us
-        # longer than the kernel's own duration in a rocprofv3 trace)
-        pairs = []
-        for _ in range(32):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            e1.record()
-            pairs.append((e0, e1))
-        torch.cuda.synchronize()
-        self.overhead_s = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2] * 1e-3
         self.empties = []  # empty pairs recorded BETWEEN the kernel brackets, i.e. with the queue as busy as it is around them
+        self.overhead_s = 0.0
+        self.passes = 0    # steps recorded (bench.py counts them: per-step totals = totals / passes)
 
     def bracket(self, name, key, launch):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -176,8 +214,8 @@ class KernelTimer:
     def _groups(self):
         torch.cuda.synchronize()
         if self.empties:
-            # the calibration taken on the idle stream at construction read 5-13 us depending on the box; the pairs taken inside
-            # the pass are what a bracket really adds (their median agrees with rocprofv3's durations of the same kernels)
+            # what a bracket adds to the kernel's own duration: the median of the empty pairs taken inside the pass (a pair on an
+            # idle stream read 5-13 us depending on the box; the in-pass median agrees with rocprofv3's durations)
             self.overhead_s = sorted(a.elapsed_time(b) for a, b in self.empties)[len(self.empties) // 2] * 1e-3
             self.empties = []
         groups = {}
@@ -189,32 +227,31 @@ class KernelTimer:
 
     @staticmethod
     def _work(name, key):
-        if name == "gemm":
-            M, N, K, dt = key
-            return "mfma", 2.0 * M * N * K, PEAK_TFLOPS[dt] * 1e12
-        B, N, D, dt = key
-        es = 2 if dt == BF16 else 4
-        if name == "fnet_ln_fwd":  # mixer + LayerNorm-1 + residual: read x, write the pre-norm tensor and x1
-            return "hbm", 3.0 * B * N * D * es, PEAK_HBM_GBS * 1e9
-        if name == "fnet_ln_bwd":  # read dout and the pre-norm tensor, write dx
-            return "hbm", 3.0 * B * N * D * es, PEAK_HBM_GBS * 1e9
-        return "hbm", 2.0 * B * N * D * es, PEAK_HBM_GBS * 1e9  # fnet_mix: read x once + write y once
+        """-> (label, shape, dtype name, bound or None, algorithmic work per launch, peak per second)"""
+        model = _WORK_MODELS.get(name)
+        if model is not None:
+            label, shape, dt, bound, work = model(key)
+            peak = PEAK_TFLOPS[dt] * 1e12 if bound == "mfma" else PEAK_HBM_GBS * 1e9
+            return label, list(shape), "bf16" if dt == BF16 else "f32", bound, work, peak
+        if name.startswith("torch:") and key and key[0] > 0:  # bench.py's own brackets around torch ops: key = (bytes,)
+            return name, [], "f32", "hbm", float(key[0]), PEAK_HBM_GBS * 1e9
+        return name.replace("spv_", ""), list(key[:4]), "-", None, 0.0, 1.0
 
     def summary(self):
         out = []
         for (name, key), (cnt, tot) in sorted(self._groups().items(), key=lambda kv: -kv[1][1]):
-            bound, work, peak = self._work(name, key)
-            ach = work * cnt / tot
-            out.append(dict(kernel=name, shape=list(key[:-1]), dtype="bf16" if key[-1] == BF16 else "f32", launches=cnt,
-                            avg_us=round(tot / cnt * 1e6, 2), total_ms=round(tot * 1e3, 3), bound=bound,
-                            achieved=round(ach / (1e12 if bound == "mfma" else 1e9), 2),
-                            unit="TFLOP/s" if bound == "mfma" else "GB/s", frac=round(ach / peak, 4),
-                            algorithmic=int(work)))
+            label, shape, dt, bound, work, peak = self._work(name, key)
+            d = dict(kernel=label, shape=shape, dtype=dt, launches=cnt, avg_us=round(tot / cnt * 1e6, 2), total_ms=round(tot * 1e3, 3))
+            if bound is not None:
+                ach = work * cnt / tot
+                d.update(bound=bound, achieved=round(ach / (1e12 if bound == "mfma" else 1e9), 2),
+                         unit="TFLOP/s" if bound == "mfma" else "GB/s", frac=round(ach / peak, 4), algorithmic=int(work))
+            out.append(d)
         return out
 
     def roofline(self):
-        """the single (kernel, shape) with the largest total time in the timed region"""
-        s = self.summary()
+        """the single modelled (kernel, shape) with the largest total time in the recorded steps"""
+        s = [d for d in self.summary() if "bound" in d]
         if not s:
             return None
         d = s[0]
@@ -224,12 +261,12 @@ class KernelTimer:
                     event_overhead_us=round(self.overhead_s * 1e6, 2))
 
 
-_timer = None
-
-
 def set_kernel_timer(t):
-    global _timer
-    _timer = t
+    _native.timer = t
+
+
+def _timing():
+    return _native.timer is not None
 
 
 def _gemm(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspace=None):
@@ -241,14 +278,6 @@ def _gemm(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspa
             splits = max(1, min(K // 64, 256 // tiles))
             if splits > 1:
                 workspace = torch.empty((splits * M * N,), dtype=torch.float32, device=c.device)
-    if _timer is not None:
-        _timer.bracket("gemm", (M, N, K, _dt(a)), lambda: _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate, splits,
-                                                                        workspace))
-    else:
-        _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate, splits, workspace)
-
-
-def _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspace=None):
     _native.call("spv_gemm_nt", _p(a), _p(b), _p(bias), _p(c), M, N, K, lda, ldb, ldc, _dt(a), _dt(c), accumulate, splits,
                  _p(workspace), _stream())
 
@@ -288,9 +317,7 @@ def _weight_grad(dh, x, rows, n, k, sink=None):
             if ws is None and splits > 1:
                 ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev)
             _native.call("spv_gemm_tn", _p(dh), _p(x), _p(dw), n, k, rows, n, k, k, F32, 0, splits, _p(ws), _stream())
-        if _timer is not None:
-            _timer.bracket("gemm", (n, k, rows, BF16), launch)
-        elif _SIDE_STREAM and 2.0 * rows * n * k >= 1e11:
+        if _SIDE_STREAM and not _timing() and 2.0 * rows * n * k >= 1e11:
             # a big weight gradient (the MHPermutMix 8192 -> 512 linear: 279 GFLOP) has no consumer inside the backward
             # chain: run it on a second HIP stream so that it fills the ramp/tail gaps of the data-gradient GEMM and
             # overlaps the HBM-bound inverse gather on the main stream (10.57 -> 10.38 ms/step).  Not worth it for the
@@ -335,7 +362,9 @@ def _sink(p):
 def _grad_buf(sink, shape, device):
     if sink is not None and not sink.used and tuple(sink.view.shape) == tuple(shape):
         sink.used = True
-        return sink.view
+        # a FRESH alias of the slot: autograd's AccumulateGrad adopts an incoming gradient as p.grad only when nothing else holds
+        # that tensor object (use_count check); returning sink.view itself made it clone the gradient and the reducer copy it back
+        return sink.view.detach()
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
@@ -531,13 +560,7 @@ def _fnet_raw(x, add_in=None):
     ws = torch.empty((wsn,), dtype=torch.float32, device=x.device) if wsn else None
     tw = _fnet_twiddle(N, x.device)
 
-    def launch():
-        _native.call("spv_fnet_mix", _p(xc), _p(y), _p(add_in), _p(tw), B, N, D, _dt(xc), _p(ws), _stream())
-
-    if _timer is not None:
-        _timer.bracket("fnet_mix", (B, N, D, _dt(xc)), launch)
-    else:
-        launch()
+    _native.call("spv_fnet_mix", _p(xc), _p(y), _p(add_in), _p(tw), B, N, D, _dt(xc), _p(ws), _stream())
     return y
 
 
@@ -981,15 +1004,8 @@ class FNetResidualFn(torch.autograd.Function):
             mean = torch.empty((B * N,), dtype=torch.float32, device=dev)
             rstd = torch.empty_like(mean)
             tw = _fnet_twiddle(N, dev)
-
-            def launch():
-                _native.call("spv_fnet_ln_fwd", _p(xc), _p(m), _p(out), _p(n1w), _p(n1b), _p(mean), _p(rstd), _p(tw), B, N, D, _dt(xc),
-                             _stream())
-
-            if _timer is not None:
-                _timer.bracket("fnet_ln_fwd", (B, N, D, _dt(xc)), launch)
-            else:
-                launch()
+            _native.call("spv_fnet_ln_fwd", _p(xc), _p(m), _p(out), _p(n1w), _p(n1b), _p(mean), _p(rstd), _p(tw), B, N, D, _dt(xc),
+                         _stream())
             ctx.saved = ("fused", m, mean, rstd, n1w, (_sink(n1w), _sink(n1b)))
             return out
         m = _fnet_raw(xc)
@@ -1012,15 +1028,8 @@ class FNetResidualFn(torch.autograd.Function):
             dn1b = _grad_buf(sinks[1], (D,), dev)
             partials = torch.empty((B * 2 * D,), dtype=torch.float32, device=dev)
             tw = _fnet_twiddle(N, dev)
-
-            def launch():
-                _native.call("spv_fnet_ln_bwd", _p(d2), _p(m), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dn1w), _p(dn1b), _p(partials),
-                             _p(tw), B, N, D, _dt(m), _stream())
-
-            if _timer is not None:
-                _timer.bracket("fnet_ln_bwd", (B, N, D, _dt(m)), launch)  # includes the tiny dgamma / dbeta fold
-            else:
-                launch()
+            _native.call("spv_fnet_ln_bwd", _p(d2), _p(m), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dn1w), _p(dn1b), _p(partials),
+                         _p(tw), B, N, D, _dt(m), _stream())
             return dx, dn1w, dn1b
         dm, dn1w, dn1b = _addln_backward(d2, sn)
         dx = _fnet_raw(dm.reshape(B, N, D), add_in=d2)  # symmetric operator; + the residual gradient, folded in
@@ -1090,13 +1099,8 @@ class PermutMixFn(torch.autograd.Function):
                      _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(d2), 0.0, 0, 0, st)
         dw = _weight_grad(dh, g, rows, n, k, s_w)  # side stream: overlaps the data gradient and the inverse gather
         if fast:
-            def launch():
-                _native.call("spv_gemm_nt_pool_bwd", _p(dh), _p(wt), _p(dg), _p(d2), pw, rows, k, n, n, wt.shape[1], k, _dt(dh),
-                             _dt(dg), _dt(d2), st)
-            if _timer is not None:
-                _timer.bracket("gemm", (rows, k, n, _dt(dh)), launch)
-            else:
-                launch()
+            _native.call("spv_gemm_nt_pool_bwd", _p(dh), _p(wt), _p(dg), _p(d2), pw, rows, k, n, n, wt.shape[1], k, _dt(dh),
+                         _dt(dg), _dt(d2), st)
         else:
             _gemm(dh, wt, None, dg, rows, k, n, n, wt.shape[1], k, accumulate=1)
         dx = torch.empty((B, d), dtype=g.dtype, device=dev)
