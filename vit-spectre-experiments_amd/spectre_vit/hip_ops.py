@@ -159,7 +159,7 @@ def _es(dt):
 # entry point -> f(ints) -> (label, shape, dtype code, bound, algorithmic work per call: flops (mfma) or compulsory bytes (hbm)).
 # ints are the integer arguments of the C-ABI call in header order (include/spv.h).
 _WORK_MODELS = {
-    "spv_gemm_nt": lambda i: ("gemm", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
+    "spv_gemm_nt": lambda i: ("gemm_acc" if i[8] else "gemm", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
     "spv_gemm_nt_grouped_rows": lambda i: ("gemm_grouped_rows", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
     "spv_gemm_nt_pool_bwd": lambda i: ("gemm_pool_bwd", i[1:4], i[7], "mfma", 2.0 * i[1] * i[2] * i[3]),
     "spv_gemm_tn": lambda i: ("gemm_tn", i[0:3], BF16, "mfma", 2.0 * i[0] * i[1] * i[2]),
