@@ -196,17 +196,7 @@ constexpr int V2XR = 8;              // at most 8 rows m in [32, 40) go through 
 typedef __attribute__((ext_vector_type(4))) short v2s16x4;
 typedef __attribute__((ext_vector_type(8))) short v2s16x8;
 
-__global__ __launch_bounds__(256) void fnet_v2_table_kernel(bf16_t* __restrict__ frag, float* __restrict__ extra,
-                                                            float* __restrict__ tw, int N) {
-    // FFT twiddles of butterfly j = 2 t32: [t32][14][2]: r = 1..7 of pass 1 (Ns = 8), then r = 1..7 of pass 2 (Ns = 64)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 32 * 14; i += gridDim.x * blockDim.x) {
-        const int t32 = i / 14, q = i % 14, r = (q % 7) + 1, j = 2 * t32;
-        float sn, cs;
-        if (q < 7) sincospif(-2.0f * (float)(r * (j & 7)) / 64.0f, &sn, &cs);
-        else sincospif(-2.0f * (float)(r * j) / 512.0f, &sn, &cs);
-        tw[2 * i] = cs;
-        tw[2 * i + 1] = sn;
-    }
+__global__ __launch_bounds__(256) void fnet_v2_table_kernel(bf16_t* __restrict__ frag, float* __restrict__ extra, int N) {
     const int nh1 = N / 2 + 1;
     auto weight = [&](int t, int m, int j) -> float {
         if (m >= nh1 || j >= 2 * ((N + 1) / 2)) return 0.0f;
@@ -235,74 +225,144 @@ __global__ __launch_bounds__(256) void fnet_v2_table_kernel(bf16_t* __restrict__
 
 __device__ __forceinline__ float v2_ld(const bf16_t* p) { return bf2f(*p); }
 
-// exp(-2 pi i r / 64) and exp(-2 pi i r / 512), r = 1..7: the step from butterfly j to j + 1 in passes 1 and 2
-__device__ constexpr float V2ROT1[7][2] = {{0.995184727f, -0.0980171403f}, {0.98078528f, -0.195090322f}, {0.956940336f, -0.290284677f}, {0.923879533f, -0.382683432f}, {0.881921264f, -0.471396737f}, {0.831469612f, -0.555570233f}, {0.773010453f, -0.634393284f}};
-__device__ constexpr float V2ROT2[7][2] = {{0.999924702f, -0.0122715383f}, {0.999698819f, -0.0245412285f}, {0.999322385f, -0.0368072229f}, {0.998795456f, -0.0490676743f}, {0.998118113f, -0.0613207363f}, {0.997290457f, -0.0735645636f}, {0.996312612f, -0.0857973123f}};
+// ---- phase B on the MFMA pipe: the 512-point FFT of a row pair z = x[2f] + i x[2f+1] as TWO matrix products --------------
+// Index split n = 16 a + b (a < 32, b < 16), k = c + 32 d (c < 32, d < 16), w_n = exp(-2 pi i / n):
+//     T[c,b]  = sum_a w_32^(a c) z[16 a + b]          stage 1: a 32-point DFT for every b        (64 x 64 real matrix B1)
+//     T'[c,b] = T[c,b] w_512^(b c)                    twiddle: lane-local on the accumulators
+//     Z[c+32d] = sum_b w_16^(b d) T'[c,b]             stage 2: a 16-point DFT for every c        (32 x 32 real matrix B2)
+// Both products are taken in the transposed form (data = A operand, DFT matrix = B operand held in registers), so that
+//   * stage 1 reads its fragments straight from the natural row layout with the transposing LDS read (rows of the [k][m] view
+//     are the 16-element groups a of a tile row; 4 consecutive groups are 128 contiguous bytes),
+//   * its accumulators hold, per lane, one c and runs of 4 consecutive b: T' leaves as 8-byte LDS stores into a [c][(part,b)]
+//     image (64 B per c, 16-byte chunks XOR-swizzled by (c >> 2) & 3: conflict-free b128 reads by stage 2),
+//   * stage 2's accumulators hold, per lane, one (part, d) and runs of 4 consecutive c = 4 consecutive frequencies k: the
+//     spectrum goes back to the tile rows (Re -> row 2f, Im -> row 2f+1, natural order) as 8-byte stores.
+// Everything is in place and WAVE-LOCAL: a wave owns whole row pairs (two per 32-row MFMA block), reads all fragments of a block
+// before it overwrites those rows (one wave's LDS instructions execute in order), so phase B needs no workgroup barrier.
+// 202 MFMAs per sample replace 3 x 33 radix-8 VALU passes (18 k of the kernel's 54 k cycles per sample in round 1).
+constexpr int V3_B1_FLOATS = 8 * 64 * 8 / 2;   // 8 fragments (4 k-steps x {Re, Im} columns) x 64 lanes x 8 bf16
+constexpr int V3_B2_FLOATS = 2 * 64 * 8 / 2;   // 2 k-steps
+constexpr int V3_TW_FLOATS = 2 * 32 * 16;      // [h][c][wr x 8, wi x 8]
+constexpr int V3_FLOATS = V3_B1_FLOATS + V3_B2_FLOATS + V3_TW_FLOATS;
 
-// One radix-8 Stockham pass (sub-transform length 2^LGNS) over one row pair, TWO butterflies per thread
-// (j = 2 t32, 2 t32 + 1; 32 threads per FFT): adjacent butterflies read and write adjacent bf16 elements, so every
-// LDS access moves a packed pair (ds_read/write_b32), and pass 0's eight outputs of a butterfly are contiguous
-// (one ds_write_b128 per component).  2.3x fewer LDS instructions than one 16-bit access per element.
-// An FFT's 32 threads are one half of ONE wave, and a wave's LDS instructions execute in order: the read phase of
-// a pass is complete before the same wave's write phase issues, so no workgroup barrier is needed inside phase B --
-// only a compiler fence (plus the lgkmcnt wait that makes the loaded registers valid anyway).
-__device__ __forceinline__ void v2_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__global__ __launch_bounds__(256) void fnet_v3_table_kernel(bf16_t* __restrict__ b1, bf16_t* __restrict__ b2, float* __restrict__ tw) {
+    const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    // B-operand fragment order of v_mfma_f32_32x32x16_bf16: lane l holds B[k = 8 (l >> 5) + e][n = l & 31]
+    for (int i = i0; i < 8 * 64 * 8; i += stride) {
+        const int e = i & 7, l = (i >> 3) & 63, nb = (i >> 9) & 1, ks = i >> 10;
+        const int part_in = ks >> 1, a = 16 * (ks & 1) + 8 * (l >> 5) + e, c = l & 31;
+        float sn, cs;
+        sincospif(2.0f * (float)((a * c) & 31) / 32.0f, &sn, &cs);
+        // w^(ac) (zr + i zi), w = cos - i sin: Re = cos zr + sin zi, Im = -sin zr + cos zi
+        const float v = nb == 0 ? (part_in == 0 ? cs : sn) : (part_in == 0 ? -sn : cs);
+        b1[i] = f2bf(v);
+    }
+    for (int i = i0; i < 2 * 64 * 8; i += stride) {
+        const int e = i & 7, l = (i >> 3) & 63, ks = i >> 9;
+        const int part_in = ks, bb = 8 * (l >> 5) + e, part_out = (l & 31) >> 4, d = l & 15;
+        float sn, cs;
+        sincospif(2.0f * (float)((bb * d) & 15) / 16.0f, &sn, &cs);
+        const float v = part_out == 0 ? (part_in == 0 ? cs : sn) : (part_in == 0 ? -sn : cs);
+        b2[i] = f2bf(v);
+    }
+    for (int i = i0; i < V3_TW_FLOATS; i += stride) {
+        const int e = i & 15, c = (i >> 4) & 31, h = i >> 9;
+        const int j = e & 7, bb = (j & 3) + 8 * (j >> 2) + 4 * h;  // accumulator register j (of 8 per row pair) -> b
+        float sn, cs;
+        sincospif(-2.0f * (float)(bb * c) / 512.0f, &sn, &cs);     // w_512^(b c) = cos - i sin
+        tw[i] = e < 8 ? cs : sn;
+    }
+}
 
-typedef float v2f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned v2_pack(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
-template <int LGNS>
-__device__ __forceinline__ void v2_pass(unsigned char* re, unsigned char* im, int t32, const cpx (&tw)[7], bool active) {
-    constexpr int NS = 1 << LGNS;
-    cpx_t<v2f2> v[8];  // component [u] = butterfly j = 2 t32 + u: the whole butterfly runs on packed v_pk_*_f32 math
-    if (active) {
+struct V3Tab {
+    bf16x8 b1[4][2];
+    bf16x8 b2[2];
+    float twr[8], twi[8];
+};
+
+__device__ __forceinline__ void v3_load_tables(V3Tab& t, const float* __restrict__ v3, int lane) {
+    const uint4* b1 = reinterpret_cast<const uint4*>(v3);
+    const uint4* b2 = reinterpret_cast<const uint4*>(v3 + V3_B1_FLOATS);
+    const float4* tw = reinterpret_cast<const float4*>(v3 + V3_B1_FLOATS + V3_B2_FLOATS) + lane * 4;  // lane = h * 32 + c
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const unsigned pr = *reinterpret_cast<const unsigned*>(re + 4 * t32 + 144 * r);  // v2_off(2 t32 + 64 r)
-            const unsigned pi = *reinterpret_cast<const unsigned*>(im + 4 * t32 + 144 * r);
-            cpx_t<v2f2> xv;
-            xv.re = v2f2{__uint_as_float(pr << 16), __uint_as_float(pr & 0xffff0000u)};
-            xv.im = v2f2{__uint_as_float(pi << 16), __uint_as_float(pi & 0xffff0000u)};
-            if (LGNS == 0 || r == 0) {
-                v[r] = xv;
-            } else {
-                // butterfly 2 t32 + 1 uses the twiddle of 2 t32 advanced by a compile-time rotation (saves 28 VGPRs)
-                const cpx rot = LGNS == 3 ? cmk(V2ROT1[r - 1][0], V2ROT1[r - 1][1]) : cmk(V2ROT2[r - 1][0], V2ROT2[r - 1][1]);
-                cpx t = tw[r - 1];
-                asm volatile("" : "+v"(t.re), "+v"(t.im));  // opaque: keeps cmul(t, rot) from being hoisted into 14 more live VGPRs
-                const cpx t1 = cmul(t, rot);
-                cpx_t<v2f2> tp;
-                tp.re = v2f2{t.re, t1.re};
-                tp.im = v2f2{t.im, t1.im};
-                v[r] = tmul(xv, tp);
-            }
-        }
-        dft8_t(v);
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) t.b1[ks][nb] = __builtin_bit_cast(bf16x8, b1[(ks * 2 + nb) * 64 + lane]);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) t.b2[ks] = __builtin_bit_cast(bf16x8, b2[ks * 64 + lane]);
+    const float4 r0 = tw[0], r1 = tw[1], i0 = tw[2], i1 = tw[3];
+    t.twr[0] = r0.x; t.twr[1] = r0.y; t.twr[2] = r0.z; t.twr[3] = r0.w; t.twr[4] = r1.x; t.twr[5] = r1.y; t.twr[6] = r1.z; t.twr[7] = r1.w;
+    t.twi[0] = i0.x; t.twi[1] = i0.y; t.twi[2] = i0.z; t.twi[3] = i0.w; t.twi[4] = i1.x; t.twi[5] = i1.y; t.twi[6] = i1.z; t.twi[7] = i1.w;
+}
+
+// byte address of T'[c][k .. k+3] (k = 16 part + b, a multiple of 4) of row pair f inside its own two tile rows
+__device__ __forceinline__ int v3_tp_addr(int f, int c, int k) {
+    return (2 * f + (c >> 4)) * V2RS + (c & 15) * 64 + (((k >> 3) ^ ((c >> 2) & 3)) << 4) + ((k & 7) << 1);
+}
+
+// one 32-row block = row pairs f0 and f0 + 1 (`two` = the second one exists); the calling wave owns tile rows 2 f0 .. 2 f0 + 3
+__device__ __forceinline__ void v3_fft_block(unsigned char* lds, int f0, bool two, const V3Tab& t, int lane) {
+    using lds_tr = v2s16x4 __attribute__((address_space(3)))*;
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int fr = two ? (g & 1) : 0, kh = g >> 1;  // an absent second pair re-reads the first one's rows; its results are dropped
+    f32x16 accR, accI;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accR[r] = 0.0f; accI[r] = 0.0f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int a0 = 16 * (ks & 1) + 8 * kh;
+        const unsigned char* row = lds + (2 * (f0 + fr) + (ks >> 1)) * V2RS;
+        const v2s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(row + v2_off(16 * (a0 + q) + 4 * pp)));
+        const v2s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(row + v2_off(16 * (a0 + 4 + q) + 4 * pp)));
+        const v2s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8 afr = __builtin_bit_cast(bf16x8, av);
+        accR = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, t.b1[ks][0], accR, 0, 0, 0);
+        accI = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, t.b1[ks][1], accI, 0, 0, 0);
     }
-    v2_wave_sync();
-    if (active) {
-        if (LGNS == 0) {
+    // twiddle + T' -> LDS.  lane: c = lane & 31, h = lane >> 5; register r: row m = (r & 3) + 8 (r >> 2) + 4 h of the block
+    // = row pair r >> 3, b = (r & 3) + 8 ((r >> 2) & 1) + 4 h
+    const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                uint4 wr, wi;
-                wr.x = v2_pack(v[0].re[u], v[1].re[u]); wr.y = v2_pack(v[2].re[u], v[3].re[u]);
-                wr.z = v2_pack(v[4].re[u], v[5].re[u]); wr.w = v2_pack(v[6].re[u], v[7].re[u]);
-                wi.x = v2_pack(v[0].im[u], v[1].im[u]); wi.y = v2_pack(v[2].im[u], v[3].im[u]);
-                wi.z = v2_pack(v[4].im[u], v[5].im[u]); wi.w = v2_pack(v[6].im[u], v[7].im[u]);
-                *reinterpret_cast<uint4*>(re + v2_off(8 * (2 * t32 + u))) = wr;  // elements 8 j .. 8 j + 7
-                *reinterpret_cast<uint4*>(im + v2_off(8 * (2 * t32 + u))) = wi;
-            }
-        } else {
-            const int j = 2 * t32;
-            const int j0 = ((j >> LGNS) << (LGNS + 3)) | (j & (NS - 1));
+    for (int fl = 0; fl < 2; ++fl) {
+        if (fl == 1 && !two) break;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                *reinterpret_cast<unsigned*>(re + v2_off(j0 + r * NS)) = v2_pack(v[r].re[0], v[r].re[1]);
-                *reinterpret_cast<unsigned*>(im + v2_off(j0 + r * NS)) = v2_pack(v[r].im[0], v[r].im[1]);
+        for (int grp = 0; grp < 2; ++grp) {
+            float re[4], im[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float tr = accR[8 * fl + 4 * grp + j], ti = accI[8 * fl + 4 * grp + j];
+                const float wr = t.twr[4 * grp + j], wi = t.twi[4 * grp + j];
+                re[j] = tr * wr - ti * wi;
+                im[j] = tr * wi + ti * wr;
             }
+            const int b0 = 8 * grp + 4 * h;
+            *reinterpret_cast<uint2*>(lds + v3_tp_addr(f0 + fl, c, b0)) = make_uint2(v2_pack(re[0], re[1]), v2_pack(re[2], re[3]));
+            *reinterpret_cast<uint2*>(lds + v3_tp_addr(f0 + fl, c, 16 + b0)) = make_uint2(v2_pack(im[0], im[1]), v2_pack(im[2], im[3]));
         }
     }
-    v2_wave_sync();
+    // stage 2 per row pair: A = T'[m = c][k = (part, b)], 16 bytes per lane and k-step
+#pragma unroll
+    for (int fl = 0; fl < 2; ++fl) {
+        if (fl == 1 && !two) break;
+        const int f = f0 + fl;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const uint4 av = *reinterpret_cast<const uint4*>(lds + v3_tp_addr(f, c, 16 * ks + 8 * h));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), t.b2[ks], acc, 0, 0, 0);
+        }
+        // lane: n = lane & 31 -> part = n >> 4, d = n & 15; register r: c = (r & 3) + 8 (r >> 2) + 4 h; frequency k = c + 32 d
+        unsigned char* orow = lds + (2 * f + ((lane & 31) >> 4)) * V2RS;
+        const int d = lane & 15;
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp)
+            *reinterpret_cast<uint2*>(orow + v2_off(32 * d + 8 * grp + 4 * h)) =
+                make_uint2(v2_pack(acc[4 * grp], acc[4 * grp + 1]), v2_pack(acc[4 * grp + 2], acc[4 * grp + 3]));
+    }
 }
 
 // LayerNorm-1 of the encoder layer fused into the mixer (reference spectre.py:66: norm1(mix(x)) + x):
@@ -326,7 +386,7 @@ constexpr float V2_LN_EPS = 1e-5f;
 template <int FUSE>
 __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                            const uint4* __restrict__ wfrag, const float* __restrict__ wextra,
-                                                           const float* __restrict__ wtw, int N, int stagger,
+                                                           const float* __restrict__ v3tab, int N, int stagger,
                                                            const bf16_t* __restrict__ add_in, FnetLn ln) {
     extern __shared__ __attribute__((aligned(16))) float lds_f32[];
     unsigned char* lds = reinterpret_cast<unsigned char*>(lds_f32);
@@ -399,31 +459,15 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
     }
     if (N & 1)
         for (int c = tid; c < 64; c += 512) *reinterpret_cast<uint4*>(lds + N * V2RS + v2_off(c * 8)) = make_uint4(0, 0, 0, 0);
-    // per-thread twiddles of passes 1 (Ns = 8) and 2 (Ns = 64) for its two butterflies j = 2 t32 + u:
-    // exp(-2 pi i r (j mod Ns) / (8 Ns)), r = 1..7
-    const int t32 = tid & 31, slot = tid >> 5;
-    cpx tw1[7], tw2[7];  // for j = 2 t32 (precomputed table); the odd butterfly's are derived in the pass
-    {
-        const float4* tp = reinterpret_cast<const float4*>(wtw + t32 * 28);
-#pragma unroll
-        for (int q4 = 0; q4 < 7; ++q4) {
-            const float4 tv = tp[q4];  // (re, im) of two consecutive twiddles
-            if (q4 * 2 < 7) tw1[q4 * 2] = cmk(tv.x, tv.y); else tw2[q4 * 2 - 7] = cmk(tv.x, tv.y);
-            if (q4 * 2 + 1 < 7) tw1[q4 * 2 + 1] = cmk(tv.z, tv.w); else tw2[q4 * 2 + 1 - 7] = cmk(tv.z, tv.w);
-        }
-    }
     __syncthreads();
     V2_STAMP(1);
 
-    // ---- B: row-pair FFTs, 16 per round
-    for (int f0 = 0; f0 < NF; f0 += 16) {
-        const int f = f0 + slot;
-        const bool active = f < NF;
-        unsigned char* re = lds + (size_t)(2 * (active ? f : 0)) * V2RS;
-        unsigned char* im = re + V2RS;
-        v2_pass<0>(re, im, t32, tw1, active);
-        v2_pass<3>(re, im, t32, tw1, active);
-        v2_pass<6>(re, im, t32, tw2, active);
+    // ---- B: row-pair FFTs on the MFMA pipe, two row pairs per block, blocks dealt round-robin to the waves (wave-local)
+    {
+        V3Tab tab;
+        v3_load_tables(tab, v3tab, lane);
+        const int nblk = (NF + 1) >> 1;
+        for (int blk = wave; blk < nblk; blk += 8) v3_fft_block(lds, 2 * blk, 2 * blk + 1 < NF, tab, lane);
     }
     V2_STAMP(2);
     __syncthreads();  // all FFT rows are final before any wave reads them as MFMA operands
@@ -693,7 +737,7 @@ __global__ __launch_bounds__(256) void haar_level_kernel(const void* __restrict_
 static int64_t v2_frag_off(int tokens) { return (int64_t)(tokens + 1) * 2 * FNET_TWS; }
 static int64_t v2_extra_off(int tokens) { return v2_frag_off(tokens) + 2 * V2KS * 64 * 8 / 2; }
 static int64_t v2_tw_off(int tokens) { return v2_extra_off(tokens) + V2XR * 2 * 16 * V2KS; }
-extern "C" int64_t spv_fnet_twiddle_floats(int tokens) { return v2_tw_off(tokens) + 32 * 28; }
+extern "C" int64_t spv_fnet_twiddle_floats(int tokens) { return v2_tw_off(tokens) + V3_FLOATS; }
 
 extern "C" int spv_fnet_make_twiddle(float* tw, int tokens, void* stream) {
     SPV_CHECK(tokens > 0, "spv_fnet_make_twiddle: tokens=%d", tokens);
@@ -701,9 +745,12 @@ extern "C" int spv_fnet_make_twiddle(float* tw, int tokens, void* stream) {
                        static_cast<hipStream_t>(stream), tw, tokens);
     SPV_LAUNCH_CHECK("spv_fnet_make_twiddle");
     hipLaunchKernelGGL(fnet_v2_table_kernel, dim3(32), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<bf16_t*>(tw + v2_frag_off(tokens)), tw + v2_extra_off(tokens), tw + v2_tw_off(tokens),
-                       tokens);
+                       reinterpret_cast<bf16_t*>(tw + v2_frag_off(tokens)), tw + v2_extra_off(tokens), tokens);
     SPV_LAUNCH_CHECK("spv_fnet_make_twiddle(v2)");
+    float* v3 = tw + v2_tw_off(tokens);
+    hipLaunchKernelGGL(fnet_v3_table_kernel, dim3(16), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<bf16_t*>(v3),
+                       reinterpret_cast<bf16_t*>(v3 + V3_B1_FLOATS), v3 + V3_B1_FLOATS + V3_B2_FLOATS);
+    SPV_LAUNCH_CHECK("spv_fnet_make_twiddle(v3)");
     return 0;
 }
 

@@ -34,6 +34,7 @@ class GradReducer:
         self._avg = self.world > 1 and dist.get_backend(process_group) == "nccl" and reduce_dtype in (None, torch.float32)
         self.adopted = 0   # gradients that arrived in the hook already living in their bucket slot (no staging copy) this step
         self.staged = 0    # gradients that had to be copied into their slot
+        self.adopted_numel = self.staged_numel = 0
         self.buckets = []  # dict(flat, params, pending, handle, stage)
         self._bucket_of = {}
         if not self.params or self.world == 1:
@@ -90,7 +91,7 @@ class GradReducer:
     # -- per step ---------------------------------------------------------------------------------
     def zero_grad(self):
         """replaces optimizer.zero_grad(set_to_none=True); re-arms the buckets."""
-        self.adopted = self.staged = 0
+        self.adopted = self.staged = self.adopted_numel = self.staged_numel = 0
         for p in self.params:
             p.grad = None
             s = getattr(p, "_spv_grad_sink", None)
@@ -115,8 +116,10 @@ class GradReducer:
         if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
             v.copy_(p.grad)  # gradient came from an op that did not write into the bucket (or autograd cloned it): stage it
             self.staged += 1
+            self.staged_numel += p.numel()
         elif p.grad is not None:
             self.adopted += 1
+            self.adopted_numel += p.numel()
         p.grad = v
         b["pending"] -= 1
         if b["pending"] == 0:
