@@ -109,7 +109,7 @@ def test_bench_multi_rank_control_flow(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 128
     assert rec["roofline"]["frac"] > 0 and "cpu_baseline" not in rec and rec["backend"] == "gloo"
-    assert rec["kernels_coverage"]["frac_of_step"] > 0.3
+    assert rec["kernels_coverage"]["frac_of_step"] > 0.05  # bs 64 over gloo: the step is mostly the CPU all-reduce here
 
 
 @pytest.mark.gpu

@@ -60,7 +60,7 @@ def oracle_step(key, img, labels, sd, layers, patch, mixer):
     return _oracle_cache[key]
 
 
-def run_and_compare(m, img, labels, ref, dtype, what):
+def run_and_compare(m, img, labels, ref, dtype, what, bound=None):
     loss_ref, logits_ref, cls_ref, grads_ref = ref
     m = m.to(dev()).train()
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
@@ -68,7 +68,7 @@ def run_and_compare(m, img, labels, ref, dtype, what):
     assert logits.dtype == torch.float32
     loss = torch.nn.CrossEntropyLoss()(logits, labels.to(dev()))
     loss.backward()
-    bound = BOUND[dtype]
+    bound = bound or BOUND[dtype]
     errs = {"logits": rel_l2(logits, logits_ref), "cls": rel_l2(cls, cls_ref)}
     assert abs(loss.item() - loss_ref) <= bound * abs(loss_ref), (loss.item(), loss_ref)
     for k, p in m.named_parameters():
@@ -155,4 +155,6 @@ def test_base_224_step_vs_oracle(dtype):
                hidden_dim=3072, dropout=0.0, activation="gelu")
     m, img, labels, sd = _setup(cfg, "permut", 8, 31)
     ref = oracle_step("base224", img, labels, sd, 12, 16, "permut")
-    run_and_compare(m, img, labels, ref, dtype, "base/224 bs8")
+    # bf16: 12 layers deep instead of 4 -- the rounding error of the residual stream grows ~ sqrt(depth): measured 1.8e-2 on the
+    # first layers' weight gradients (Small, 4 layers: 1.1e-2), logits 6.7e-3; fp32 4.8e-6
+    run_and_compare(m, img, labels, ref, dtype, "base/224 bs8", bound=None if dtype == torch.float32 else 2.5e-2)

@@ -893,6 +893,170 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     store_acc_tile<TO>(acc, smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// TN contraction, LDS-DMA variant: the weight gradients of the encoder layers, dW[768 x 512] = dh^T . x over 33 280 rows
+// (backward of layers.py:86).  Same output tile (128 x 128) as gemm_tn_kernel, but
+//   * operands staged by global_load_lds_dwordx4 (no staging VGPRs, no ds_write) into a THREE-stage LDS ring of 64 k rows,
+//     two stages in flight, ONE barrier per K-tile behind a counted vmcnt;
+//   * 8 waves: two K-groups (k-steps {0,1} / {2,3} of every K-tile) x 2 x 2 wave tiles of 64 x 64, so every SIMD holds two
+//     waves and one wave's transposing LDS reads run under the other's MFMAs; the two partial tiles meet in LDS at the end
+//     (each wave finishes 32 of its 64 rows);
+//   * DMA writes are lane-linear (a wave instruction = 4 k rows of 256 B), so rows cannot be padded: the 16-byte chunk index is
+//     XOR-ed with (row & 3) << 2 on the per-lane SOURCE address and again on the fragment read -- the 4 k rows x 2 column blocks
+//     that one half of a ds_read_b64_tr_b16 touches then cover 8 disjoint 32-byte bank ranges = all 64 banks.
+// Needs M, N multiples of 128 and K, the split-K slices multiples of 64 (the layer shapes); anything else: gemm_tn_kernel.
+constexpr int TDK = 64;                      // k rows per stage
+constexpr int TD_STAGE = 2 * TDK * 256;      // A tile + B tile, 256 B per k row each
+constexpr int TD_NST = 3;
+constexpr int TD_SMEM = TD_NST * TD_STAGE;   // 96 KiB (the epilogue's 64 KiB exchange + 8 x 8.5 KiB stages reuse it)
+
+template <typename TO>
+__global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
+                                                          float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc,
+                                                          int k_per_split, int accumulate, int tiles_n, int tiles_mn, int nsplit) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char td_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);  // whole K-slices per XCD: a slice's operand rows hit in that L2
+    const int split = lin / tiles_mn, tile = lin % tiles_mn;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+
+    // DMA: per stage and operand 16 wave instructions of 4 k rows; this wave issues instructions 2 wave, 2 wave + 1
+    const bf16_t* asrc[2];
+    const bf16_t* bsrc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int R = 4 * (2 * wave + t) + (lane >> 4);          // k row of the stage written by this lane
+        const int c = (lane & 15) ^ ((R & 3) << 2);              // logical 16-byte chunk that belongs at this LDS position
+        asrc[t] = A + (size_t)R * lda + m0 + c * 8;
+        bsrc[t] = B + (size_t)R * ldb + n0 + c * 8;
+    }
+    auto stage = [&](int buf, int k0) __attribute__((always_inline)) {
+        unsigned char* sa = td_smem + buf * TD_STAGE + (2 * wave) * 1024;
+        unsigned char* sb = sa + TDK * 256;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[t] + (size_t)k0 * lda),
+                                             (__attribute__((address_space(3))) void*)(sa + t * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[t] + (size_t)k0 * ldb),
+                                             (__attribute__((address_space(3))) void*)(sb + t * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // transposing-read geometry (as gemm_tn_kernel): group g = lane >> 4 covers columns 16 (g & 1) + [0,16) of a 32-wide MFMA
+    // block and k half g >> 1; lane 4 q + p of the group supplies row q, columns 4 p .. 4 p + 3
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    // byte offset inside a k row of MFMA block x (32 columns), swizzled for row & 3 == q: chunk = 4 x + 2 (g & 1) + (pp >> 1)
+    auto col_off = [&](int x) { return (((4 * x + 2 * (g & 1) + (pp >> 1)) ^ (q << 2)) << 4) + ((pp & 1) << 3); };
+    int offa[2], offb[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+        offa[f] = (8 * (g >> 1) + q) * 256 + col_off(2 * wm + f);
+        offb[f] = TDK * 256 + (8 * (g >> 1) + q) * 256 + col_off(2 * wn + f);
+    }
+    using lds_tr = s16x4 __attribute__((address_space(3)))*;
+    auto frag = [&](const unsigned char* p) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(p + 4 * 256));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+
+    if (kbeg < kend) stage(0, kbeg);
+    if (kbeg + TDK < kend) stage(1, kbeg + TDK);
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += TDK) {
+        // this wave's share of stage `buf` has landed (the younger stage's 4 pieces may still fly) ...
+        if (k0 + TDK < kend) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... everyone's has, and everyone is done reading the stage refilled next
+        if (k0 + 2 * TDK < kend) stage(buf == 0 ? 2 : buf - 1, k0 + 2 * TDK);
+        const unsigned char* st = td_smem + buf * TD_STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int ks = 2 * kg + s2;
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f] = frag(st + ks * 16 * 256 + offa[f]);
+                b[f] = frag(st + ks * 16 * 256 + offb[f]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    // ---- the two K-groups meet: wave (kg, wm, wn) finishes rows [32 kg, 32 kg + 32) of its 64 x 64 block, i.e. acc[kg][*] plus
+    // the partner's acc[kg][*]; each wave hands over the half it does not finish (8 KiB per wave, lane-linear)
+    __syncthreads();  // every wave is out of the K loop: the ring is free
+    {
+        float* xch = reinterpret_cast<float*>(td_smem) + (size_t)wave * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64 + lane] = kg == 0 ? acc[1][j][r] : acc[0][j][r];
+    }
+    __syncthreads();
+    f32x16 fin[2];
+    {
+        const float* xch = reinterpret_cast<const float*>(td_smem) + (size_t)(wave ^ 4) * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fin[j][r] = (kg == 0 ? acc[0][j][r] : acc[1][j][r]) + xch[(j * 16 + r) * 64 + lane];
+    }
+    __syncthreads();  // exchange area read: reuse it as the wave-private store stages
+    {
+        // 32 x 64 block of this wave -> fp32 LDS stage [32][68] -> every lane leaves with 8 consecutive columns of a row
+        constexpr int SLD = 68;
+        float* stg = reinterpret_cast<float*>(td_smem + wave * 9216);
+        const int fh = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * fh) * SLD + j * 32 + (lane & 31)] = fin[j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private stage: the wave's own writes are done before it reads
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int qd = lane + 64 * t;
+            const int lr = qd >> 3, c8 = qd & 7;
+            const int row = m0 + wm * 64 + kg * 32 + lr;
+            const int col0 = n0 + wn * 64 + c8 * 8;
+            const float4 lo = *reinterpret_cast<const float4*>(stg + lr * SLD + c8 * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(stg + lr * SLD + c8 * 8 + 4);
+            float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            if (ws != nullptr) {
+                float4* wp = reinterpret_cast<float4*>(ws + ((size_t)split * M + row) * N + col0);
+                wp[0] = lo;
+                wp[1] = hi;
+                continue;
+            }
+            TO* cp = C + (size_t)row * ldc + col0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (accumulate) v[u] += load_out<TO>(cp + u);
+                store_out<TO>(cp + u, v[u]);
+            }
+        }
+    }
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                             TO* __restrict__ C, int M, int N, int ldc, int splits,
@@ -1097,6 +1261,21 @@ extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, 
         splits = cdiv(K, k_per_split);
     }
     float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
+    static const int use_dma = getenv("SPV_TN_DMA") ? atoi(getenv("SPV_TN_DMA")) : 1;  // A/B aid: 0 = register-staged kernel
+    if (use_dma && M % BM == 0 && N % BN == 0 && K % TDK == 0 && k_per_split % TDK == 0 && (ws != nullptr || ldc % 4 == 0)) {
+        const int nwg = tiles_m * tiles_n * splits;
+        if (out_dtype == SPV_BF16) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_SMEM);
+            hipLaunchKernelGGL((gemm_tn_dma_kernel<bf16_t>), dim3(nwg), dim3(512), TD_SMEM, st, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, ws,
+                               M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n, splits);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_dma_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, TD_SMEM);
+            hipLaunchKernelGGL((gemm_tn_dma_kernel<float>), dim3(nwg), dim3(512), TD_SMEM, st, (const bf16_t*)A, (const bf16_t*)B, (float*)C, ws,
+                               M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n, splits);
+        }
+        SPV_LAUNCH_CHECK("spv_gemm_tn(dma)");
+        SPV_COUNT_PATH(SPV_PATH_GEMM_TN_DMA);
+    } else {
     dim3 grid(tiles_m * tiles_n * splits);
     static const int depth = getenv("SPV_TN_DEPTH") ? atoi(getenv("SPV_TN_DEPTH")) : 3;  // tuning aid: 1 = one K-tile in flight
 #define SPV_TN(TOV, DV)                                                                                                     \
@@ -1109,6 +1288,7 @@ extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, 
     }
 #undef SPV_TN
     SPV_LAUNCH_CHECK("spv_gemm_tn");
+    }
     if (splits > 1) {
         int blocks = (int)std::min<int64_t>(((int64_t)M * N / ((N & 3) == 0 ? 4 : 1) + 255) / 256, 2048);
         if (out_dtype == SPV_BF16)
