@@ -571,8 +571,8 @@ __device__ __forceinline__ void a3_store_block(bf16_t* o, const f32x16& v) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
         uint2 w;
-        w.x = (unsigned)f2bf(v[4 * qd]) | ((unsigned)f2bf(v[4 * qd + 1]) << 16);
-        w.y = (unsigned)f2bf(v[4 * qd + 2]) | ((unsigned)f2bf(v[4 * qd + 3]) << 16);
+        w.x = pack_bf16x2(v[4 * qd], v[4 * qd + 1]);
+        w.y = pack_bf16x2(v[4 * qd + 2], v[4 * qd + 3]);
         *reinterpret_cast<uint2*>(o + 8 * qd) = w;
     }
 }

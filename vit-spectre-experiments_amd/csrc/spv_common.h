@@ -37,6 +37,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 
+// two floats -> one dword of two bf16 (lo in bits 0..15): ONE v_cvt_pk_bf16_f32.  (Converting the halves separately and joining them
+// with shift + or compiles to four VALU instructions; the row kernels and the FNet mixer are VALU bound.)
+typedef __bf16 spv_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float spv_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const spv_f32x2 f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, spv_bf16x2));
+}
+
 template <typename T> struct io;
 template <> struct io<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -59,8 +68,8 @@ template <> struct io<bf16_t> {
     }
     static __device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) {
         uint2 t;
-        t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        t.x = pack_bf16x2(v[0], v[1]);
+        t.y = pack_bf16x2(v[2], v[3]);
         *reinterpret_cast<uint2*>(p) = t;
     }
 };

@@ -184,13 +184,19 @@ __device__ unsigned long long* g_fnet_stamps = nullptr;
             g_fnet_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                           \
     } while (0)
+#define V2_STAMP_RT(i)                                                                               \
+    do {                                                                                             \
+        if (g_fnet_stamps && (threadIdx.x & 63) == 0)                                                \
+            g_fnet_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define V2_STAMP(i)
+#define V2_STAMP_RT(i)
 #endif
 constexpr int V2D = 512;
-constexpr int V2RS = V2D * 2 + 128;  // LDS row stride in bytes: 16 B of padding after every 64 elements, so that the
-                                     // radix-8 pass with Ns = 8 (stores 128 B apart across lanes) is bank-conflict free
-__device__ __forceinline__ int v2_off(int idx) { return 2 * idx + 16 * (idx >> 6); }  // byte offset of element idx in a row
+constexpr int V2RS = V2D * 2 + 64;   // LDS row stride in bytes: 64 B of padding per row = a quarter of the 256-byte bank window, so that
+                                     // the four rows (and the row pair two rows further) a transposing read touches cover disjoint banks
+__device__ __forceinline__ int v2_off(int idx) { return 2 * idx; }  // byte offset of element idx in a row
 constexpr int V2KS = 5;              // MFMA k-steps: 80 >= 2 * ceil(79 / 2) planar rows
 constexpr int V2XR = 8;              // at most 8 rows m in [32, 40) go through the VALU path
 typedef __attribute__((ext_vector_type(4))) short v2s16x4;
@@ -209,16 +215,19 @@ __global__ __launch_bounds__(256) void fnet_v2_table_kernel(bf16_t* __restrict__
         return t == 0 ? ((j & 1) ? w1i : w1r) : ((j & 1) ? w2i : w2r);
     };
     const int nfrag = 2 * V2KS * 64 * 8;
-    const int nextra = V2XR * 2 * 16 * V2KS;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfrag + nextra; i += gridDim.x * blockDim.x) {
+    const int nfragx = V2KS * 64 * 8;
+    bf16_t* fragx = reinterpret_cast<bf16_t*>(extra);  // [ks][lane][8] bf16 in the (former fp32) extras region, same byte size
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nfrag + nfragx; i += gridDim.x * blockDim.x) {
         if (i < nfrag) {
-            // A-operand fragment order of v_mfma_f32_32x32x16_bf16: lane l holds W[m = l & 31][j = 16 ks + 8 (l >> 5) + e]
+            // fragment order of v_mfma_f32_32x32x16_bf16 (the A operand of W . Z == the B operand of Z^T . W^T): lane l holds
+            // W[m = l & 31][j = 16 ks + 8 (l >> 5) + e]
             const int e = i & 7, l = (i >> 3) & 63, ks = (i >> 9) % V2KS, t = i / (V2KS * 512);
             frag[i] = f2bf(weight(t, l & 31, 16 * ks + 8 * (l >> 5) + e));
         } else {
+            // third accumulator: column 0 carries W1[32], column 1 W2[32], the other 30 columns are zero
             const int q = i - nfrag;
-            const int j = q % (16 * V2KS), t = (q / (16 * V2KS)) & 1, me = q / (2 * 16 * V2KS);
-            extra[q] = weight(t, 32 + me, j);
+            const int e = q & 7, l = (q >> 3) & 63, ks = q >> 9, col = l & 31;
+            fragx[q] = f2bf(col < 2 ? weight(col, 32, 16 * ks + 8 * (l >> 5) + e) : 0.0f);
         }
     }
 }
@@ -240,22 +249,21 @@ __device__ __forceinline__ float v2_ld(const bf16_t* p) { return bf2f(*p); }
 // Everything is in place and WAVE-LOCAL: a wave owns whole row pairs (two per 32-row MFMA block), reads all fragments of a block
 // before it overwrites those rows (one wave's LDS instructions execute in order), so phase B needs no workgroup barrier.
 // 202 MFMAs per sample replace 3 x 33 radix-8 VALU passes (18 k of the kernel's 54 k cycles per sample in round 1).
-constexpr int V3_B1_FLOATS = 8 * 64 * 8 / 2;   // 8 fragments (4 k-steps x {Re, Im} columns) x 64 lanes x 8 bf16
+constexpr int V3_B1_FLOATS = 4 * 64 * 8 / 2;   // 4 fragments: cos, sin of 2 pi a c / 32 for a < 16 / a >= 16 (x 64 lanes x 8 bf16)
 constexpr int V3_B2_FLOATS = 2 * 64 * 8 / 2;   // 2 k-steps
-constexpr int V3_TW_FLOATS = 2 * 32 * 16;      // [h][c][wr x 8, wi x 8]
-constexpr int V3_FLOATS = V3_B1_FLOATS + V3_B2_FLOATS + V3_TW_FLOATS;
+constexpr int V3_FLOATS = V3_B1_FLOATS + V3_B2_FLOATS;
 
-__global__ __launch_bounds__(256) void fnet_v3_table_kernel(bf16_t* __restrict__ b1, bf16_t* __restrict__ b2, float* __restrict__ tw) {
+__global__ __launch_bounds__(256) void fnet_v3_table_kernel(bf16_t* __restrict__ b1, bf16_t* __restrict__ b2) {
     const int i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     // B-operand fragment order of v_mfma_f32_32x32x16_bf16: lane l holds B[k = 8 (l >> 5) + e][n = l & 31]
-    for (int i = i0; i < 8 * 64 * 8; i += stride) {
-        const int e = i & 7, l = (i >> 3) & 63, nb = (i >> 9) & 1, ks = i >> 10;
-        const int part_in = ks >> 1, a = 16 * (ks & 1) + 8 * (l >> 5) + e, c = l & 31;
+    // stage 1: w^(ac) (zr + i zi), w = cos - i sin: Re = cos zr + sin zi, Im = -sin zr + cos zi.  Four fragments are kept
+    // ([trig: cos, sin][a half]); the -sin ones are the sin ones with the sign bits flipped.
+    for (int i = i0; i < 4 * 64 * 8; i += stride) {
+        const int e = i & 7, l = (i >> 3) & 63, ah = (i >> 9) & 1, trig = i >> 10;
+        const int a = 16 * ah + 8 * (l >> 5) + e, c = l & 31;
         float sn, cs;
         sincospif(2.0f * (float)((a * c) & 31) / 32.0f, &sn, &cs);
-        // w^(ac) (zr + i zi), w = cos - i sin: Re = cos zr + sin zi, Im = -sin zr + cos zi
-        const float v = nb == 0 ? (part_in == 0 ? cs : sn) : (part_in == 0 ? -sn : cs);
-        b1[i] = f2bf(v);
+        b1[i] = f2bf(trig == 0 ? cs : sn);
     }
     for (int i = i0; i < 2 * 64 * 8; i += stride) {
         const int e = i & 7, l = (i >> 3) & 63, ks = i >> 9;
@@ -265,16 +273,9 @@ __global__ __launch_bounds__(256) void fnet_v3_table_kernel(bf16_t* __restrict__
         const float v = part_out == 0 ? (part_in == 0 ? cs : sn) : (part_in == 0 ? -sn : cs);
         b2[i] = f2bf(v);
     }
-    for (int i = i0; i < V3_TW_FLOATS; i += stride) {
-        const int e = i & 15, c = (i >> 4) & 31, h = i >> 9;
-        const int j = e & 7, bb = (j & 3) + 8 * (j >> 2) + 4 * h;  // accumulator register j (of 8 per row pair) -> b
-        float sn, cs;
-        sincospif(-2.0f * (float)(bb * c) / 512.0f, &sn, &cs);     // w_512^(b c) = cos - i sin
-        tw[i] = e < 8 ? cs : sn;
-    }
 }
 
-__device__ __forceinline__ unsigned v2_pack(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ unsigned v2_pack(float lo, float hi) { return pack_bf16x2(lo, hi); }
 
 struct V3Tab {
     bf16x8 b1[4][2];
@@ -285,16 +286,28 @@ struct V3Tab {
 __device__ __forceinline__ void v3_load_tables(V3Tab& t, const float* __restrict__ v3, int lane) {
     const uint4* b1 = reinterpret_cast<const uint4*>(v3);
     const uint4* b2 = reinterpret_cast<const uint4*>(v3 + V3_B1_FLOATS);
-    const float4* tw = reinterpret_cast<const float4*>(v3 + V3_B1_FLOATS + V3_B2_FLOATS) + lane * 4;  // lane = h * 32 + c
+    // k-step ks = 2 part_in + a half; column block nb = part_out:  (re -> re) cos, (re -> im) -sin, (im -> re) sin, (im -> im) cos
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) t.b1[ks][nb] = __builtin_bit_cast(bf16x8, b1[(ks * 2 + nb) * 64 + lane]);
+    for (int ah = 0; ah < 2; ++ah) {
+        const uint4 cs = b1[(0 * 2 + ah) * 64 + lane], sn = b1[(1 * 2 + ah) * 64 + lane];
+        const uint4 ns = make_uint4(sn.x ^ 0x80008000u, sn.y ^ 0x80008000u, sn.z ^ 0x80008000u, sn.w ^ 0x80008000u);
+        t.b1[ah][0] = __builtin_bit_cast(bf16x8, cs);
+        t.b1[ah][1] = __builtin_bit_cast(bf16x8, ns);
+        t.b1[2 + ah][0] = __builtin_bit_cast(bf16x8, sn);
+        t.b1[2 + ah][1] = __builtin_bit_cast(bf16x8, cs);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) t.b2[ks] = __builtin_bit_cast(bf16x8, b2[ks * 64 + lane]);
-    const float4 r0 = tw[0], r1 = tw[1], i0 = tw[2], i1 = tw[3];
-    t.twr[0] = r0.x; t.twr[1] = r0.y; t.twr[2] = r0.z; t.twr[3] = r0.w; t.twr[4] = r1.x; t.twr[5] = r1.y; t.twr[6] = r1.z; t.twr[7] = r1.w;
-    t.twi[0] = i0.x; t.twi[1] = i0.y; t.twi[2] = i0.z; t.twi[3] = i0.w; t.twi[4] = i1.x; t.twi[5] = i1.y; t.twi[6] = i1.z; t.twi[7] = i1.w;
+    // twiddle w_512^(b c) = cos - i sin of 2 pi b c / 512 for this lane's c = lane & 31 and its 8 values of b (accumulator register
+    // j of a row pair -> b = (j & 3) + 8 (j >> 2) + 4 (lane >> 5)); v_sin / v_cos take revolutions
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int bb = (j & 3) + 8 * (j >> 2) + 4 * h;
+        const float rev = (float)(bb * c) * (1.0f / 512.0f);
+        t.twr[j] = __builtin_amdgcn_cosf(rev);
+        t.twi[j] = -__builtin_amdgcn_sinf(rev);
+    }
 }
 
 // byte address of T'[c][k .. k+3] (k = 16 part + b, a multiple of 4) of row pair f inside its own two tile rows
@@ -342,7 +355,10 @@ __device__ __forceinline__ void v3_fft_block(unsigned char* lds, int f0, bool tw
             *reinterpret_cast<uint2*>(lds + v3_tp_addr(f0 + fl, c, 16 + b0)) = make_uint2(v2_pack(im[0], im[1]), v2_pack(im[2], im[3]));
         }
     }
-    // stage 2 per row pair: A = T'[m = c][k = (part, b)], 16 bytes per lane and k-step
+    // stage 2 per row pair: T'[c][k = (part, b)] (16 bytes per lane and k-step) is the B operand here and the 16-point DFT matrix the
+    // A operand, so that a lane owns ONE c = one residue of the frequency k = c + 32 d and its registers run over (part, d): the
+    // 32 lanes of a register write 32 CONSECUTIVE frequencies (64 contiguous bytes of a tile row).  (In the transposed form a lane
+    // owned one d and the 16 lanes of an 8-byte store hit two bank positions: 8-way conflicts, 58 % of all LDS cycles of the kernel.)
 #pragma unroll
     for (int fl = 0; fl < 2; ++fl) {
         if (fl == 1 && !two) break;
@@ -352,16 +368,25 @@ __device__ __forceinline__ void v3_fft_block(unsigned char* lds, int f0, bool tw
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const uint4 av = *reinterpret_cast<const uint4*>(lds + v3_tp_addr(f, c, 16 * ks + 8 * h));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), t.b2[ks], acc, 0, 0, 0);
+            const uint4 tv = *reinterpret_cast<const uint4*>(lds + v3_tp_addr(f, c, 16 * ks + 8 * h));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.b2[ks], __builtin_bit_cast(bf16x8, tv), acc, 0, 0, 0);
         }
-        // lane: n = lane & 31 -> part = n >> 4, d = n & 15; register r: c = (r & 3) + 8 (r >> 2) + 4 h; frequency k = c + 32 d
-        unsigned char* orow = lds + (2 * f + ((lane & 31) >> 4)) * V2RS;
-        const int d = lane & 15;
+        // register r: row m = (r & 3) + 8 (r >> 2) + 4 h of the product = (part = m >> 4, d = m & 15); column = c; frequency k = c + 32 d.
+        // Neighbouring lanes hold neighbouring frequencies: even lanes take over the odd neighbour's value of registers 0-7 (Re), odd
+        // lanes the even neighbour's of registers 8-15 (Im), so every lane leaves with 8 packed pairs: 8 four-byte stores, not 16 two-byte
+        bf16_t* orow = reinterpret_cast<bf16_t*>(lds + (2 * f) * V2RS);
+        const bool odd = lane & 1;
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp)
-            *reinterpret_cast<uint2*>(orow + v2_off(32 * d + 8 * grp + 4 * h)) =
-                make_uint2(v2_pack(acc[4 * grp], acc[4 * grp + 1]), v2_pack(acc[4 * grp + 2], acc[4 * grp + 3]));
+        for (int r = 0; r < 8; ++r) {
+            // quad_perm [1,0,3,2]: the value of the lane's neighbour
+            const float nre = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[r]), 0xB1, 0xF, 0xF, true));
+            const float nim = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc[8 + r]), 0xB1, 0xF, 0xF, true));
+            const int d = (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;
+            // even lane: Re pair (own c, neighbour c + 1) -> row 2 f; odd lane: Im pair (neighbour c - 1, own c) -> row 2 f + 1
+            const unsigned pr = odd ? pack_bf16x2(nim, acc[8 + r]) : pack_bf16x2(acc[r], nre);
+            unsigned char* dst = reinterpret_cast<unsigned char*>(orow) + (odd ? V2RS : 0) + v2_off(32 * d + (c & ~1));
+            *reinterpret_cast<unsigned*>(dst) = pr;
+        }
     }
 }
 
@@ -383,9 +408,12 @@ struct FnetLn {
 };
 constexpr float V2_LN_EPS = 1e-5f;
 
+constexpr int V2IT = 9;                  // row-chunk iterations of the 512 threads over 65 rows x 64 chunks of 16 B
+constexpr int V2YRS = V2D * 2 + 16;      // row stride of the Y stage (phase C -> D): 260 dwords = 4 mod 32 banks between rows
+
 template <int FUSE>
 __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
-                                                           const uint4* __restrict__ wfrag, const float* __restrict__ wextra,
+                                                           const uint4* __restrict__ wfrag, const uint4* __restrict__ wfragx,
                                                            const float* __restrict__ v3tab, int N, int stagger,
                                                            const bf16_t* __restrict__ add_in, FnetLn ln) {
     extern __shared__ __attribute__((aligned(16))) float lds_f32[];
@@ -394,6 +422,7 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
     const size_t base = (size_t)blockIdx.x * N * V2D;
     const int NF = (N + 1) >> 1, JR = 2 * NF, nh1 = N / 2 + 1;
 
+    V2_STAMP_RT(10);
     // Phase stagger: with batch = 2 x CUs every CU gets exactly two workgroups and, launched together, they would all
     // load, then all compute, then all store -- HBM idle while the VALUs work and vice versa.  The second half of the
     // grid (the second workgroup of each CU under in-order dispatch; a performance assumption only) sleeps through the
@@ -401,10 +430,14 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
     if (stagger > 0 && blockIdx.x >= (gridDim.x >> 1))
         for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
     V2_STAMP(0);
-    // ---- A: x -> LDS (bf16), pad row of an odd N zeroed
+    // the DFT-matrix fragments of phase B: requested first, so that they arrive under the tile's own loads
+    V3Tab tab;
+    if (FUSE != 2) v3_load_tables(tab, v3tab, lane);  // (the backward's staging loop needs the registers: it asks afterwards)
+    // ---- A: x -> LDS (bf16), pad row of an odd N zeroed.  Thread tid owns chunk tid & 63 of rows (tid >> 6) + 8 i: all of an
+    // iteration batch's loads are issued before the first use (a dependent load per loop trip cost a memory round trip each)
+    const int ch = tid & 63;
     if (FUSE == 2) {
         // x is the gradient wrt x1 = LN(m) + x0: d m = rstd (dy g - mean(dy g) - xhat mean(dy g xhat)); one row per wave step
-        const int ch = tid & 63;
         float gam[8], accg[8], accb[8];
         {
             const float4 g0 = *reinterpret_cast<const float4*>(ln.gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(ln.gamma + ch * 8 + 4);
@@ -412,32 +445,47 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) { accg[u] = 0.0f; accb[u] = 0.0f; }
-        for (int c = tid; c < N * 64; c += 512) {
-            const int row = c >> 6;
-            const uint4 dv = *reinterpret_cast<const uint4*>(x + base + (size_t)row * V2D + ch * 8);
-            const uint4 mv = *reinterpret_cast<const uint4*>(ln.m_in + base + (size_t)row * V2D + ch * 8);
-            const float mean = ln.mean[(size_t)blockIdx.x * N + row], rstd = ln.rstd[(size_t)blockIdx.x * N + row];
-            const unsigned dw[4] = {dv.x, dv.y, dv.z, dv.w}, mw[4] = {mv.x, mv.y, mv.z, mv.w};
-            float xh[8], t[8];
-            float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float d0 = __uint_as_float(dw[u] << 16), d1 = __uint_as_float(dw[u] & 0xffff0000u);
-                xh[2 * u] = (__uint_as_float(mw[u] << 16) - mean) * rstd;
-                xh[2 * u + 1] = (__uint_as_float(mw[u] & 0xffff0000u) - mean) * rstd;
-                accg[2 * u] += d0 * xh[2 * u]; accg[2 * u + 1] += d1 * xh[2 * u + 1];
-                accb[2 * u] += d0; accb[2 * u + 1] += d1;
-                t[2 * u] = d0 * gam[2 * u]; t[2 * u + 1] = d1 * gam[2 * u + 1];
-                s1 += t[2 * u] + t[2 * u + 1];
-                s2 += t[2 * u] * xh[2 * u] + t[2 * u + 1] * xh[2 * u + 1];
+        for (int i0 = 0; i0 < V2IT; i0 += 3) {
+            uint4 dvv[3], mvv[3];
+            float mn[3], rs[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int row = min(wave + 8 * (i0 + i), N - 1);  // rows past N: a valid address, the value is not used
+                dvv[i] = *reinterpret_cast<const uint4*>(x + base + (size_t)row * V2D + ch * 8);
+                mvv[i] = *reinterpret_cast<const uint4*>(ln.m_in + base + (size_t)row * V2D + ch * 8);
+                mn[i] = ln.mean[(size_t)blockIdx.x * N + row];
+                rs[i] = ln.rstd[(size_t)blockIdx.x * N + row];
             }
-            const float m1 = wave_sum(s1) * (1.0f / V2D), m2 = wave_sum(s2) * (1.0f / V2D);
-            unsigned o[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                o[u] = (unsigned)f2bf(rstd * (t[2 * u] - m1 - xh[2 * u] * m2)) | ((unsigned)f2bf(rstd * (t[2 * u + 1] - m1 - xh[2 * u + 1] * m2)) << 16);
-            *reinterpret_cast<uint4*>(lds + row * V2RS + v2_off(ch * 8)) = make_uint4(o[0], o[1], o[2], o[3]);
+            for (int i = 0; i < 3; ++i) {
+                const int row = wave + 8 * (i0 + i);
+                if (row >= N) continue;
+                const uint4 dv = dvv[i], mv = mvv[i];
+                const float mean = mn[i], rstd = rs[i];
+                const unsigned dw[4] = {dv.x, dv.y, dv.z, dv.w}, mw[4] = {mv.x, mv.y, mv.z, mv.w};
+                float xh[8], t[8];
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float d0 = __uint_as_float(dw[u] << 16), d1 = __uint_as_float(dw[u] & 0xffff0000u);
+                    xh[2 * u] = (__uint_as_float(mw[u] << 16) - mean) * rstd;
+                    xh[2 * u + 1] = (__uint_as_float(mw[u] & 0xffff0000u) - mean) * rstd;
+                    accg[2 * u] += d0 * xh[2 * u]; accg[2 * u + 1] += d1 * xh[2 * u + 1];
+                    accb[2 * u] += d0; accb[2 * u + 1] += d1;
+                    t[2 * u] = d0 * gam[2 * u]; t[2 * u + 1] = d1 * gam[2 * u + 1];
+                    s1 += t[2 * u] + t[2 * u + 1];
+                    s2 += t[2 * u] * xh[2 * u] + t[2 * u + 1] * xh[2 * u + 1];
+                }
+                const float m1 = wave_sum(s1) * (1.0f / V2D), m2 = wave_sum(s2) * (1.0f / V2D);
+                unsigned o[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    o[u] = pack_bf16x2(rstd * (t[2 * u] - m1 - xh[2 * u] * m2), rstd * (t[2 * u + 1] - m1 - xh[2 * u + 1] * m2));
+                *reinterpret_cast<uint4*>(lds + row * V2RS + v2_off(ch * 8)) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
         }
+        v3_load_tables(tab, v3tab, lane);  // arrive under the column-sum rounds below
         // column sums: the 8 waves hold the same 512 columns; meet in the 4 KiB behind the tile, in wave order
         float* red = reinterpret_cast<float*>(lds + (size_t)std::max(2 * ((N + 1) / 2), 2 * (N / 2 + 1)) * V2RS);
         for (int w = 0; w < 8; ++w) {
@@ -452,9 +500,16 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
         }
         for (int c = tid; c < 2 * V2D; c += 512) ln.partials[(size_t)blockIdx.x * 2 * V2D + c] = red[c];
     } else {
-        for (int c = tid; c < N * 64; c += 512) {
-            const int row = c >> 6, ch = c & 63;
-            *reinterpret_cast<uint4*>(lds + row * V2RS + v2_off(ch * 8)) = *reinterpret_cast<const uint4*>(x + base + (size_t)row * V2D + ch * 8);
+        uint4 xv[V2IT];
+#pragma unroll
+        for (int i = 0; i < V2IT; ++i) {
+            const int row = min(wave + 8 * i, N - 1);  // rows past N: a valid address, the value is not stored
+            xv[i] = *reinterpret_cast<const uint4*>(x + base + (size_t)row * V2D + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < V2IT; ++i) {
+            const int row = wave + 8 * i;
+            if (row < N) *reinterpret_cast<uint4*>(lds + row * V2RS + v2_off(ch * 8)) = xv[i];
         }
     }
     if (N & 1)
@@ -464,8 +519,6 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
 
     // ---- B: row-pair FFTs on the MFMA pipe, two row pairs per block, blocks dealt round-robin to the waves (wave-local)
     {
-        V3Tab tab;
-        v3_load_tables(tab, v3tab, lane);
         const int nblk = (NF + 1) >> 1;
         for (int blk = wave; blk < nblk; blk += 8) v3_fft_block(lds, 2 * blk, 2 * blk + 1 < NF, tab, lane);
     }
@@ -473,22 +526,34 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
     __syncthreads();  // all FFT rows are final before any wave reads them as MFMA operands
     V2_STAMP(3);
 
-    // ---- C: Y1 = W1 . Z, Y2 = W2 . Z for m < 32 on the MFMA pipe; this wave owns columns [64 wave, 64 wave + 64)
-    f32x16 acc[2][2];
+    // ---- C: Y1 = W1 . Z, Y2 = W2 . Z on the MFMA pipe, TRANSPOSED (the tile is the A operand, W^T the B operand): this wave owns
+    // columns [64 wave, 64 wave + 64); an accumulator then holds, per lane, one output row m = lane & 31 and runs of 4 consecutive
+    // columns, which leave as 8-byte LDS stores.  Row m = 32 (the 33rd of N = 65) rides in ONE more accumulator for both column
+    // blocks: its B fragment carries W1[32], W2[32] in columns 0, 1 for block 0 and -- the same registers moved two lanes up -- in
+    // columns 2, 3 for block 1 (round 1: 80 LDS reads + 160 FMAs per thread on the VALU).
+    f32x16 acc[2][2], accx;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { acc[0][0][r] = 0.0f; acc[0][1][r] = 0.0f; acc[1][0][r] = 0.0f; acc[1][1][r] = 0.0f; accx[r] = 0.0f; }
+    const bool extra = nh1 > 32;
     {
         using lds_ptr = v2s16x4 __attribute__((address_space(3)))*;
         const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
         const int colb = v2_off(wave * 64 + 16 * (g & 1) + 4 * pp);  // byte offset of this lane's 4 columns inside a row
 #pragma unroll
         for (int ks = 0; ks < V2KS; ++ks) {
-            const bf16x8 a1 = __builtin_bit_cast(bf16x8, wfrag[(0 * V2KS + ks) * 64 + lane]);
-            const bf16x8 a2 = __builtin_bit_cast(bf16x8, wfrag[(1 * V2KS + ks) * 64 + lane]);
+            const bf16x8 w1 = __builtin_bit_cast(bf16x8, wfrag[(0 * V2KS + ks) * 64 + lane]);
+            const bf16x8 w2 = __builtin_bit_cast(bf16x8, wfrag[(1 * V2KS + ks) * 64 + lane]);
+            bf16x8 wx[2];
+            {
+                const uint4 wa = wfragx[ks * 64 + lane];
+                wx[0] = __builtin_bit_cast(bf16x8, wa);
+                uint4 wb;  // row_shr:2 with zero fill: lanes 2, 3 (34, 35) take over lanes 0, 1 (32, 33); everything else is zero either way
+                wb.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wa.x, 0x112, 0xF, 0xF, true);
+                wb.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wa.y, 0x112, 0xF, 0xF, true);
+                wb.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wa.z, 0x112, 0xF, 0xF, true);
+                wb.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wa.w, 0x112, 0xF, 0xF, true);
+                wx[1] = __builtin_bit_cast(bf16x8, wb);
+            }
             const int j_lo = min(16 * ks + 8 * (g >> 1) + q, JR - 1);      // rows past JR carry zero weights: clamp
             const int j_hi = min(16 * ks + 8 * (g >> 1) + q + 4, JR - 1);
 #pragma unroll
@@ -496,72 +561,99 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
                 const v2s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + j_lo * V2RS + colb + cb * 64));
                 const v2s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(lds + j_hi * V2RS + colb + cb * 64));
                 const v2s16x8 bv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                const bf16x8 bfr = __builtin_bit_cast(bf16x8, bv);
-                acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr, acc[cb][0], 0, 0, 0);
-                acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bfr, acc[cb][1], 0, 0, 0);
+                const bf16x8 zf = __builtin_bit_cast(bf16x8, bv);
+                acc[cb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf, w1, acc[cb][0], 0, 0, 0);
+                acc[cb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf, w2, acc[cb][1], 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zf, wx[cb], accx, 0, 0, 0);  // (zero weights when there is no row 32)
             }
         }
     }
     V2_STAMP(4);
-    // row m = 32 (the only one past the MFMA block for tokens <= 65) on the VALU: fp32 weights through the scalar cache
-    // (compile-time offsets -> batched s_load), 80 independent LDS reads in flight; thread tid owns column k = tid
-    float ex0 = 0.0f, ex1 = 0.0f;
-    if (nh1 > 32) {
-#pragma unroll 16
-        for (int j = 0; j < 16 * V2KS; ++j) {
-            const float z = v2_ld(reinterpret_cast<const bf16_t*>(lds + min(j, JR - 1) * V2RS + v2_off(tid)));  // weights are 0 past JR
-            ex0 = fmaf(wextra[j], z, ex0);
-            ex1 = fmaf(wextra[16 * V2KS + j], z, ex1);
+    // the residual rows of phase D (forward: the mixer's own input; backward / plain: add_in) are requested here, all at once and two
+    // barriers early: the barriers below wait for LDS only (s_waitcnt lgkmcnt + s_barrier, not __syncthreads, whose fence would also
+    // wait for these loads), so the rows travel under the stage write (a load per loop trip was a memory round trip per row)
+    const bf16_t* resp = FUSE == 1 ? ln.res : add_in;
+    uint4 rv[V2IT];
+#pragma unroll
+    for (int i = 0; i < V2IT; ++i) rv[i] = make_uint4(0, 0, 0, 0);  // bf16 zeros (plain mixer call: nothing to add)
+    if (resp != nullptr) {
+#pragma unroll
+        for (int i = 0; i < V2IT; ++i) {
+            const int r = min(wave + 8 * i, N - 1);
+            rv[i] = *reinterpret_cast<const uint4*>(resp + base + (size_t)r * V2D + ch * 8);
         }
     }
     V2_STAMP(5);
-    __syncthreads();  // every read of Z is done: its LDS becomes the Y stage (Y1 rows [0,nh1), Y2 rows [nh1, 2 nh1))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every read of Z is done: its LDS becomes the Y stage (Y1 rows [0,nh1), Y2 rows [nh1, 2 nh1))
     V2_STAMP(6);
 
     {
-        const int h = lane >> 5;
+        // accumulator register r of lane (h = lane >> 5, m = lane & 31): column (r & 3) + 8 (r >> 2) + 4 h of the 32-column block
+        const int h = lane >> 5, m = lane & 31;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < 2; ++cb) {
+            const int colbyte = (wave * 64 + cb * 32 + 4 * h) * 2;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t) {
+                if (m < nh1) {
+                    unsigned char* yr = lds + (t * nh1 + m) * V2YRS + colbyte;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < nh1)
-                        reinterpret_cast<bf16_t*>(lds + (t * nh1 + m) * V2RS)[wave * 64 + cb * 32 + (lane & 31)] = f2bf(acc[cb][t][r]);
+                    for (int grp = 0; grp < 4; ++grp)
+                        *reinterpret_cast<uint2*>(yr + 16 * grp) =
+                            make_uint2(v2_pack(acc[cb][t][4 * grp], acc[cb][t][4 * grp + 1]), v2_pack(acc[cb][t][4 * grp + 2], acc[cb][t][4 * grp + 3]));
                 }
-        if (nh1 > 32) {
-            reinterpret_cast<bf16_t*>(lds + (0 * nh1 + 32) * V2RS)[tid] = f2bf(ex0);
-            reinterpret_cast<bf16_t*>(lds + (1 * nh1 + 32) * V2RS)[tid] = f2bf(ex1);
+            }
+        }
+        if (extra && m < 4) {  // columns 0, 1 of the fifth accumulator = Y1[32], Y2[32] of column block 0; columns 2, 3 of block 1
+            unsigned char* yr = lds + ((m & 1) * nh1 + 32) * V2YRS + (wave * 64 + (m >> 1) * 32 + 4 * h) * 2;
+#pragma unroll
+            for (int grp = 0; grp < 4; ++grp)
+                *reinterpret_cast<uint2*>(yr + 16 * grp) =
+                    make_uint2(v2_pack(accx[4 * grp], accx[4 * grp + 1]), v2_pack(accx[4 * grp + 2], accx[4 * grp + 3]));
         }
     }
     V2_STAMP(7);
-    __syncthreads();
+    float gg[8], bb[8];
+    if (FUSE == 1) {
+        const int k0 = ch * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(ln.gamma + k0), g1 = *reinterpret_cast<const float4*>(ln.gamma + k0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(ln.beta + k0), b1 = *reinterpret_cast<const float4*>(ln.beta + k0 + 4);
+        gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     V2_STAMP(8);
 
-    // ---- D: combine mirrored halves, 8 consecutive frequencies per lane, 16-byte stores
-    for (int c = tid; c < N * 64; c += 512) {
-        const int r = c >> 6, k0 = (c & 63) * 8;
+    // ---- D: combine mirrored halves, 8 consecutive frequencies per lane, 16-byte stores; row r = wave + 8 i is this wave's
+#pragma unroll
+    for (int i = 0; i < V2IT; ++i) {
+        const int r = wave + 8 * i, k0 = ch * 8;
+        if (r >= N) continue;
         const bool low = 2 * r <= N;           // r <= N / 2
         const int m = low ? r : N - r;
-        const bf16_t* fwd = reinterpret_cast<const bf16_t*>(lds + ((low ? 0 : 1) * nh1 + m) * V2RS);  // read at k
-        const bf16_t* mir = reinterpret_cast<const bf16_t*>(lds + ((low ? 1 : 0) * nh1 + m) * V2RS);  // read at D - k
+        const bf16_t* fwd = reinterpret_cast<const bf16_t*>(lds + ((low ? 0 : 1) * nh1 + m) * V2YRS);  // read at k
+        const bf16_t* mir = reinterpret_cast<const bf16_t*>(lds + ((low ? 1 : 0) * nh1 + m) * V2YRS);  // read at D - k
         const uint4 fv = *reinterpret_cast<const uint4*>(fwd + k0);
         const unsigned fw[4] = {fv.x, fv.y, fv.z, fv.w};
-        uint4 av = make_uint4(0, 0, 0, 0);  // bf16 zeros
-        if (add_in != nullptr) av = *reinterpret_cast<const uint4*>(add_in + base + (size_t)r * V2D + k0);
-        const unsigned aw[4] = {av.x, av.y, av.z, av.w};
+        // the mirror partners of k0 .. k0 + 7 are D - k0, D - k0 - 1, ..., D - k0 - 7: element 0 of chunk (64 - ch) & 63, then elements
+        // 7 .. 1 of chunk 63 - ch -- one 16-byte and one 2-byte LDS read instead of eight 2-byte ones with their index arithmetic
+        const uint4 mv = *reinterpret_cast<const uint4*>(mir + 8 * (63 - ch));
+        const float mf[8] = {v2_ld(mir + ((V2D - k0) & (V2D - 1))), __uint_as_float(mv.w & 0xffff0000u), __uint_as_float(mv.w << 16),
+                             __uint_as_float(mv.z & 0xffff0000u), __uint_as_float(mv.z << 16), __uint_as_float(mv.y & 0xffff0000u),
+                             __uint_as_float(mv.y << 16), __uint_as_float(mv.x & 0xffff0000u)};
+        const unsigned aw[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
         unsigned o[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float a0 = __uint_as_float(fw[u] << 16) + v2_ld(mir + ((V2D - (k0 + 2 * u)) & (V2D - 1))) + __uint_as_float(aw[u] << 16);
-            const float a1 = __uint_as_float(fw[u] & 0xffff0000u) + v2_ld(mir + ((V2D - (k0 + 2 * u + 1)) & (V2D - 1))) +
-                             __uint_as_float(aw[u] & 0xffff0000u);
-            o[u] = (unsigned)f2bf(a0) | ((unsigned)f2bf(a1) << 16);
-        }
         if (FUSE == 1) {
             // the row (64 chunks) is this wave's: LayerNorm over the bf16-rounded mixer output (exactly what the unfused
             // add+LayerNorm kernel would read back), then + residual
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a0 = __uint_as_float(fw[u] << 16) + mf[2 * u];
+                const float a1 = __uint_as_float(fw[u] & 0xffff0000u) + mf[2 * u + 1];
+                o[u] = pack_bf16x2(a0, a1);
+            }
             *reinterpret_cast<uint4*>(ln.prenorm + base + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
             float v[8];
             float sm = 0.0f;
@@ -577,21 +669,24 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
             for (int u = 0; u < 8; ++u) { const float d = v[u] - mean; sq += d * d; }
             const float rstd = rsqrtf(wave_sum(sq) * (1.0f / V2D) + V2_LN_EPS);
             if (lane == 0) { ln.mean[(size_t)blockIdx.x * N + r] = mean; ln.rstd[(size_t)blockIdx.x * N + r] = rstd; }
-            const float4 g0 = *reinterpret_cast<const float4*>(ln.gamma + k0), g1 = *reinterpret_cast<const float4*>(ln.gamma + k0 + 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(ln.beta + k0), b1 = *reinterpret_cast<const float4*>(ln.beta + k0 + 4);
-            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            const uint4 rv = *reinterpret_cast<const uint4*>(ln.res + base + (size_t)r * V2D + k0);
-            const unsigned rw[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float e0 = (v[2 * u] - mean) * rstd * gg[2 * u] + bb[2 * u] + __uint_as_float(rw[u] << 16);
-                const float e1 = (v[2 * u + 1] - mean) * rstd * gg[2 * u + 1] + bb[2 * u + 1] + __uint_as_float(rw[u] & 0xffff0000u);
-                o[u] = (unsigned)f2bf(e0) | ((unsigned)f2bf(e1) << 16);
+                const float e0 = (v[2 * u] - mean) * rstd * gg[2 * u] + bb[2 * u] + __uint_as_float(aw[u] << 16);
+                const float e1 = (v[2 * u + 1] - mean) * rstd * gg[2 * u + 1] + bb[2 * u + 1] + __uint_as_float(aw[u] & 0xffff0000u);
+                o[u] = pack_bf16x2(e0, e1);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a0 = __uint_as_float(fw[u] << 16) + mf[2 * u] + __uint_as_float(aw[u] << 16);
+                const float a1 = __uint_as_float(fw[u] & 0xffff0000u) + mf[2 * u + 1] + __uint_as_float(aw[u] & 0xffff0000u);
+                o[u] = pack_bf16x2(a0, a1);
             }
         }
         *reinterpret_cast<uint4*>(y + base + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
     V2_STAMP(9);
+    V2_STAMP_RT(11);
 }
 
 // dgamma / dbeta of the fused backward: out[c] = sum over workgroup slabs, 16 columns x 64 slab rows per workgroup
@@ -748,8 +843,8 @@ extern "C" int spv_fnet_make_twiddle(float* tw, int tokens, void* stream) {
                        reinterpret_cast<bf16_t*>(tw + v2_frag_off(tokens)), tw + v2_extra_off(tokens), tokens);
     SPV_LAUNCH_CHECK("spv_fnet_make_twiddle(v2)");
     float* v3 = tw + v2_tw_off(tokens);
-    hipLaunchKernelGGL(fnet_v3_table_kernel, dim3(16), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<bf16_t*>(v3),
-                       reinterpret_cast<bf16_t*>(v3 + V3_B1_FLOATS), v3 + V3_B1_FLOATS + V3_B2_FLOATS);
+    hipLaunchKernelGGL(fnet_v3_table_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<bf16_t*>(v3),
+                       reinterpret_cast<bf16_t*>(v3 + V3_B1_FLOATS));
     SPV_LAUNCH_CHECK("spv_fnet_make_twiddle(v3)");
     return 0;
 }
@@ -782,7 +877,7 @@ extern "C" int spv_fnet_mix(const void* x, void* y, const void* add_in, const fl
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         SPV_COUNT_PATH(SPV_PATH_FNET_MFMA);
     hipLaunchKernelGGL(fnet_mfma_kernel<0>, dim3(batch), dim3(512), lds, st, static_cast<const bf16_t*>(x), static_cast<bf16_t*>(y),
-                           reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)), twiddle + v2_extra_off(tokens),
+                           reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)), reinterpret_cast<const uint4*>(twiddle + v2_extra_off(tokens)),
                            twiddle + v2_tw_off(tokens), tokens, v2_stagger, static_cast<const bf16_t*>(add_in), FnetLn{});
         SPV_LAUNCH_CHECK("spv_fnet_mix(v2)");
         return 0;
@@ -862,6 +957,10 @@ extern "C" int spv_fnet_ln_supported(int tokens, int dim, int dtype) {
     return (!off && dtype == SPV_BF16 && dim == V2D && tokens >= 2 && tokens <= 65) ? 1 : 0;
 }
 
+static int fnet_ln_stagger(int batch) {
+    static const int env = getenv("SPV_FNET_LN_STAGGER") ? atoi(getenv("SPV_FNET_LN_STAGGER")) : 0;  // x 8128 cycles; tuning aid
+    return batch >= 512 ? env : 0;
+}
 static size_t fnet_v2_lds(int tokens) { return (size_t)std::max(2 * ((tokens + 1) / 2), 2 * (tokens / 2 + 1)) * V2RS; }
 
 extern "C" int spv_fnet_ln_fwd(const void* x, void* prenorm, void* out, const float* gamma, const float* beta, float* mean, float* rstd,
@@ -874,8 +973,8 @@ extern "C" int spv_fnet_ln_fwd(const void* x, void* prenorm, void* out, const fl
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     SPV_COUNT_PATH(SPV_PATH_FNET_MFMA);
     hipLaunchKernelGGL(fnet_mfma_kernel<1>, dim3(batch), dim3(512), fnet_v2_lds(tokens), st, static_cast<const bf16_t*>(x),
-                       static_cast<bf16_t*>(out), reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)), twiddle + v2_extra_off(tokens),
-                       twiddle + v2_tw_off(tokens), tokens, 0, static_cast<const bf16_t*>(nullptr), ln);
+                       static_cast<bf16_t*>(out), reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)), reinterpret_cast<const uint4*>(twiddle + v2_extra_off(tokens)),
+                       twiddle + v2_tw_off(tokens), tokens, fnet_ln_stagger(batch), static_cast<const bf16_t*>(nullptr), ln);
     SPV_LAUNCH_CHECK("spv_fnet_ln_fwd");
     return 0;
 }
@@ -893,7 +992,7 @@ extern "C" int spv_fnet_ln_bwd(const void* dout, const void* prenorm, const floa
     SPV_COUNT_PATH(SPV_PATH_FNET_MFMA);
     hipLaunchKernelGGL(fnet_mfma_kernel<2>, dim3(batch), dim3(512), fnet_v2_lds(tokens) + 2 * V2D * sizeof(float), st,
                        static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dx), reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)),
-                       twiddle + v2_extra_off(tokens), twiddle + v2_tw_off(tokens), tokens, 0, static_cast<const bf16_t*>(dout), ln);
+                       reinterpret_cast<const uint4*>(twiddle + v2_extra_off(tokens)), twiddle + v2_tw_off(tokens), tokens, fnet_ln_stagger(batch), static_cast<const bf16_t*>(dout), ln);
     SPV_LAUNCH_CHECK("spv_fnet_ln_bwd");
     hipLaunchKernelGGL(fnet_ln_fold_kernel, dim3(2 * V2D / 16), dim3(1024), 0, st, partials, dgamma, dbeta, batch);
     SPV_LAUNCH_CHECK("spv_fnet_ln_bwd(fold)");

@@ -158,10 +158,10 @@ __device__ __forceinline__ void store_acc_tile(f32x16 (*acc)[2], unsigned char* 
                         v[6] += __uint_as_float(old.w << 16); v[7] += __uint_as_float(old.w & 0xffff0000u);
                     }
                     uint4 o;
-                    o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                    o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                    o.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
-                    o.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    o.z = pack_bf16x2(v[4], v[5]);
+                    o.w = pack_bf16x2(v[6], v[7]);
                     *reinterpret_cast<uint4*>(cp) = o;
                 } else {
                     float4* c4 = reinterpret_cast<float4*>(cp);
@@ -659,10 +659,10 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
                     w[6] += __uint_as_float(old.w << 16); w[7] += __uint_as_float(old.w & 0xffff0000u);
                 }
                 u32x4 o;
-                o.x = (unsigned)f2bf(w[0]) | ((unsigned)f2bf(w[1]) << 16);
-                o.y = (unsigned)f2bf(w[2]) | ((unsigned)f2bf(w[3]) << 16);
-                o.z = (unsigned)f2bf(w[4]) | ((unsigned)f2bf(w[5]) << 16);
-                o.w = (unsigned)f2bf(w[6]) | ((unsigned)f2bf(w[7]) << 16);
+                o.x = pack_bf16x2(w[0], w[1]);
+                o.y = pack_bf16x2(w[2], w[3]);
+                o.z = pack_bf16x2(w[4], w[5]);
+                o.w = pack_bf16x2(w[6], w[7]);
                 // s_nop 1: the hardware reads a 16-byte store's data registers a state after issue; hipcc pads nothing inside an asm string
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(o) : "memory");
             };

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ x
             unsigned o[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                o[u] = (unsigned)f2bf(__uint_as_float(w[u] << 16) * sc[2 * u]) | ((unsigned)f2bf(__uint_as_float(w[u] & 0xffff0000u) * sc[2 * u + 1]) << 16);
+                o[u] = pack_bf16x2(__uint_as_float(w[u] << 16) * sc[2 * u], __uint_as_float(w[u] & 0xffff0000u) * sc[2 * u + 1]);
             *reinterpret_cast<uint4*>(static_cast<bf16_t*>(y) + i) = make_uint4(o[0], o[1], o[2], o[3]);
         } else {
             const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(x) + i);
