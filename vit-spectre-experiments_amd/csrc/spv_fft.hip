@@ -249,8 +249,12 @@ __device__ __forceinline__ float v2_ld(const bf16_t* p) { return bf2f(*p); }
 // Everything is in place and WAVE-LOCAL: a wave owns whole row pairs (two per 32-row MFMA block), reads all fragments of a block
 // before it overwrites those rows (one wave's LDS instructions execute in order), so phase B needs no workgroup barrier.
 // 202 MFMAs per sample replace 3 x 33 radix-8 VALU passes (18 k of the kernel's 54 k cycles per sample in round 1).
-constexpr int V3_B1_FLOATS = 4 * 64 * 8 / 2;   // 4 fragments: cos, sin of 2 pi a c / 32 for a < 16 / a >= 16 (x 64 lanes x 8 bf16)
-constexpr int V3_B2_FLOATS = 2 * 64 * 8 / 2;   // 2 k-steps
+// The DFT matrices are the same for every sample, so their bf16 rounding is a COHERENT error of the operator (0.2 % per entry): it
+// does not average out over the batch the way the data's rounding does, and doubled the error of the deepest parameter gradients
+// (rel-L2 1.1e-2 -> 2.3e-2 on the embedding's frequency weights at bs 512).  Each matrix is therefore kept as hi + lo bf16 parts
+// (error 2^-17) and every product takes two MFMAs.
+constexpr int V3_B1_FLOATS = 8 * 64 * 8 / 2;   // [part: hi, lo][trig: cos, sin][a half] fragments of 2 pi a c / 32 (x 64 lanes x 8 bf16)
+constexpr int V3_B2_FLOATS = 4 * 64 * 8 / 2;   // [part: hi, lo][k-step]
 constexpr int V3_FLOATS = V3_B1_FLOATS + V3_B2_FLOATS;
 
 __global__ __launch_bounds__(256) void fnet_v3_table_kernel(bf16_t* __restrict__ b1, bf16_t* __restrict__ b2) {
@@ -258,46 +262,49 @@ __global__ __launch_bounds__(256) void fnet_v3_table_kernel(bf16_t* __restrict__
     // B-operand fragment order of v_mfma_f32_32x32x16_bf16: lane l holds B[k = 8 (l >> 5) + e][n = l & 31]
     // stage 1: w^(ac) (zr + i zi), w = cos - i sin: Re = cos zr + sin zi, Im = -sin zr + cos zi.  Four fragments are kept
     // ([trig: cos, sin][a half]); the -sin ones are the sin ones with the sign bits flipped.
-    for (int i = i0; i < 4 * 64 * 8; i += stride) {
-        const int e = i & 7, l = (i >> 3) & 63, ah = (i >> 9) & 1, trig = i >> 10;
+    for (int i = i0; i < 8 * 64 * 8; i += stride) {
+        const int e = i & 7, l = (i >> 3) & 63, ah = (i >> 9) & 1, trig = (i >> 10) & 1, lo = i >> 11;
         const int a = 16 * ah + 8 * (l >> 5) + e, c = l & 31;
         float sn, cs;
         sincospif(2.0f * (float)((a * c) & 31) / 32.0f, &sn, &cs);
-        b1[i] = f2bf(trig == 0 ? cs : sn);
+        const float v = trig == 0 ? cs : sn;
+        const bf16_t hi = f2bf(v);
+        b1[i] = lo ? f2bf(v - bf2f(hi)) : hi;
     }
-    for (int i = i0; i < 2 * 64 * 8; i += stride) {
-        const int e = i & 7, l = (i >> 3) & 63, ks = i >> 9;
+    for (int i = i0; i < 4 * 64 * 8; i += stride) {
+        const int e = i & 7, l = (i >> 3) & 63, ks = (i >> 9) & 1, lo = i >> 10;
         const int part_in = ks, bb = 8 * (l >> 5) + e, part_out = (l & 31) >> 4, d = l & 15;
         float sn, cs;
         sincospif(2.0f * (float)((bb * d) & 15) / 16.0f, &sn, &cs);
         const float v = part_out == 0 ? (part_in == 0 ? cs : sn) : (part_in == 0 ? -sn : cs);
-        b2[i] = f2bf(v);
+        const bf16_t hi = f2bf(v);
+        b2[i] = lo ? f2bf(v - bf2f(hi)) : hi;
     }
 }
 
 __device__ __forceinline__ unsigned v2_pack(float lo, float hi) { return pack_bf16x2(lo, hi); }
 
-struct V3Tab {
-    bf16x8 b1[4][2];
-    bf16x8 b2[2];
+struct V3Tab {          // stage 1: DFT-32 fragments + the twiddles applied to its accumulators
+    uint4 b1[2][2][2];  // [hi / lo][cos / sin][a half]
     float twr[8], twi[8];
 };
+struct V3Tab2 {         // stage 2: DFT-16 fragments; asked for only once stage 1 is through (the two sets never live together)
+    uint4 b2[2][2];     // [hi / lo][k-step]
+};
+__device__ __forceinline__ bf16x8 v3_frag(uint4 v, bool negate) {
+    if (negate) v = make_uint4(v.x ^ 0x80008000u, v.y ^ 0x80008000u, v.z ^ 0x80008000u, v.w ^ 0x80008000u);
+    return __builtin_bit_cast(bf16x8, v);
+}
 
 __device__ __forceinline__ void v3_load_tables(V3Tab& t, const float* __restrict__ v3, int lane) {
     const uint4* b1 = reinterpret_cast<const uint4*>(v3);
-    const uint4* b2 = reinterpret_cast<const uint4*>(v3 + V3_B1_FLOATS);
-    // k-step ks = 2 part_in + a half; column block nb = part_out:  (re -> re) cos, (re -> im) -sin, (im -> re) sin, (im -> im) cos
 #pragma unroll
-    for (int ah = 0; ah < 2; ++ah) {
-        const uint4 cs = b1[(0 * 2 + ah) * 64 + lane], sn = b1[(1 * 2 + ah) * 64 + lane];
-        const uint4 ns = make_uint4(sn.x ^ 0x80008000u, sn.y ^ 0x80008000u, sn.z ^ 0x80008000u, sn.w ^ 0x80008000u);
-        t.b1[ah][0] = __builtin_bit_cast(bf16x8, cs);
-        t.b1[ah][1] = __builtin_bit_cast(bf16x8, ns);
-        t.b1[2 + ah][0] = __builtin_bit_cast(bf16x8, sn);
-        t.b1[2 + ah][1] = __builtin_bit_cast(bf16x8, cs);
+    for (int lo = 0; lo < 2; ++lo) {
+#pragma unroll
+        for (int trig = 0; trig < 2; ++trig)
+#pragma unroll
+            for (int ah = 0; ah < 2; ++ah) t.b1[lo][trig][ah] = b1[((lo * 2 + trig) * 2 + ah) * 64 + lane];
     }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) t.b2[ks] = __builtin_bit_cast(bf16x8, b2[ks * 64 + lane]);
     // twiddle w_512^(b c) = cos - i sin of 2 pi b c / 512 for this lane's c = lane & 31 and its 8 values of b (accumulator register
     // j of a row pair -> b = (j & 3) + 8 (j >> 2) + 4 (lane >> 5)); v_sin / v_cos take revolutions
     const int c = lane & 31, h = lane >> 5;
@@ -310,13 +317,21 @@ __device__ __forceinline__ void v3_load_tables(V3Tab& t, const float* __restrict
     }
 }
 
+__device__ __forceinline__ void v3_load_tables2(V3Tab2& t, const float* __restrict__ v3, int lane) {
+    const uint4* b2 = reinterpret_cast<const uint4*>(v3 + V3_B1_FLOATS);
+#pragma unroll
+    for (int lo = 0; lo < 2; ++lo)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) t.b2[lo][ks] = b2[(lo * 2 + ks) * 64 + lane];
+}
+
 // byte address of T'[c][k .. k+3] (k = 16 part + b, a multiple of 4) of row pair f inside its own two tile rows
 __device__ __forceinline__ int v3_tp_addr(int f, int c, int k) {
     return (2 * f + (c >> 4)) * V2RS + (c & 15) * 64 + (((k >> 3) ^ ((c >> 2) & 3)) << 4) + ((k & 7) << 1);
 }
 
 // one 32-row block = row pairs f0 and f0 + 1 (`two` = the second one exists); the calling wave owns tile rows 2 f0 .. 2 f0 + 3
-__device__ __forceinline__ void v3_fft_block(unsigned char* lds, int f0, bool two, const V3Tab& t, int lane) {
+__device__ __forceinline__ void v3_stage1_block(unsigned char* lds, int f0, bool two, const V3Tab& t, int lane) {
     using lds_tr = v2s16x4 __attribute__((address_space(3)))*;
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
     const int fr = two ? (g & 1) : 0, kh = g >> 1;  // an absent second pair re-reads the first one's rows; its results are dropped
@@ -331,8 +346,13 @@ __device__ __forceinline__ void v3_fft_block(unsigned char* lds, int f0, bool tw
         const v2s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr)(row + v2_off(16 * (a0 + 4 + q) + 4 * pp)));
         const v2s16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const bf16x8 afr = __builtin_bit_cast(bf16x8, av);
-        accR = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, t.b1[ks][0], accR, 0, 0, 0);
-        accI = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, t.b1[ks][1], accI, 0, 0, 0);
+        // k-step ks = 2 part_in + a half:  (re -> re) cos, (re -> im) -sin, (im -> re) sin, (im -> im) cos; hi + lo parts of each
+        const int pin = ks >> 1, ah = ks & 1;
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) {
+            accR = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, v3_frag(t.b1[lo][pin][ah], false), accR, 0, 0, 0);
+            accI = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr, v3_frag(t.b1[lo][1 - pin][ah], pin == 0), accI, 0, 0, 0);
+        }
     }
     // twiddle + T' -> LDS.  lane: c = lane & 31, h = lane >> 5; register r: row m = (r & 3) + 8 (r >> 2) + 4 h of the block
     // = row pair r >> 3, b = (r & 3) + 8 ((r >> 2) & 1) + 4 h
@@ -355,6 +375,10 @@ __device__ __forceinline__ void v3_fft_block(unsigned char* lds, int f0, bool tw
             *reinterpret_cast<uint2*>(lds + v3_tp_addr(f0 + fl, c, 16 + b0)) = make_uint2(v2_pack(im[0], im[1]), v2_pack(im[2], im[3]));
         }
     }
+}
+
+__device__ __forceinline__ void v3_stage2_block(unsigned char* lds, int f0, bool two, const V3Tab2& t, int lane) {
+    const int c = lane & 31, h = lane >> 5;
     // stage 2 per row pair: T'[c][k = (part, b)] (16 bytes per lane and k-step) is the B operand here and the 16-point DFT matrix the
     // A operand, so that a lane owns ONE c = one residue of the frequency k = c + 32 d and its registers run over (part, d): the
     // 32 lanes of a register write 32 CONSECUTIVE frequencies (64 contiguous bytes of a tile row).  (In the transposed form a lane
@@ -369,7 +393,8 @@ __device__ __forceinline__ void v3_fft_block(unsigned char* lds, int f0, bool tw
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const uint4 tv = *reinterpret_cast<const uint4*>(lds + v3_tp_addr(f, c, 16 * ks + 8 * h));
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t.b2[ks], __builtin_bit_cast(bf16x8, tv), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, t.b2[0][ks]), __builtin_bit_cast(bf16x8, tv), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, t.b2[1][ks]), __builtin_bit_cast(bf16x8, tv), acc, 0, 0, 0);
         }
         // register r: row m = (r & 3) + 8 (r >> 2) + 4 h of the product = (part = m >> 4, d = m & 15); column = c; frequency k = c + 32 d.
         // Neighbouring lanes hold neighbouring frequencies: even lanes take over the odd neighbour's value of registers 0-7 (Re), odd
@@ -520,7 +545,10 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
     // ---- B: row-pair FFTs on the MFMA pipe, two row pairs per block, blocks dealt round-robin to the waves (wave-local)
     {
         const int nblk = (NF + 1) >> 1;
-        for (int blk = wave; blk < nblk; blk += 8) v3_fft_block(lds, 2 * blk, 2 * blk + 1 < NF, tab, lane);
+        for (int blk = wave; blk < nblk; blk += 8) v3_stage1_block(lds, 2 * blk, 2 * blk + 1 < NF, tab, lane);
+        V3Tab2 tab2;
+        v3_load_tables2(tab2, v3tab, lane);
+        for (int blk = wave; blk < nblk; blk += 8) v3_stage2_block(lds, 2 * blk, 2 * blk + 1 < NF, tab2, lane);
     }
     V2_STAMP(2);
     __syncthreads();  // all FFT rows are final before any wave reads them as MFMA operands
@@ -843,7 +871,7 @@ extern "C" int spv_fnet_make_twiddle(float* tw, int tokens, void* stream) {
                        reinterpret_cast<bf16_t*>(tw + v2_frag_off(tokens)), tw + v2_extra_off(tokens), tokens);
     SPV_LAUNCH_CHECK("spv_fnet_make_twiddle(v2)");
     float* v3 = tw + v2_tw_off(tokens);
-    hipLaunchKernelGGL(fnet_v3_table_kernel, dim3(8), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<bf16_t*>(v3),
+    hipLaunchKernelGGL(fnet_v3_table_kernel, dim3(16), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<bf16_t*>(v3),
                        reinterpret_cast<bf16_t*>(v3 + V3_B1_FLOATS));
     SPV_LAUNCH_CHECK("spv_fnet_make_twiddle(v3)");
     return 0;

@@ -910,6 +910,8 @@ constexpr int TD_STAGE = 2 * TDK * 256;      // A tile + B tile, 256 B per k row
 constexpr int TD_NST = 3;
 constexpr int TD_SMEM = TD_NST * TD_STAGE;   // 96 KiB (the epilogue's 64 KiB exchange + 8 x 8.5 KiB stages reuse it)
 
+// (Tried and dropped: a ninth wave touching the slice's operand lines six K-tiles ahead, on the theory that every K-tile's first
+// request pays an HBM round trip -- no change, 56.5 vs 55.4 us: the loop is bound by DMA ISSUE on the 64 B/clk L1 path, below.)
 template <typename TO>
 __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
                                                           float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc,
@@ -982,7 +984,14 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const bf16_t* __restri
         if (k0 + TDK < kend) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // ... everyone's has, and everyone is done reading the stage refilled next
-        if (k0 + 2 * TDK < kend) stage(buf == 0 ? 2 : buf - 1, k0 + 2 * TDK);
+        // The four DMA pieces of K-tile t + 2 go out ONE behind every MFMA pair of K-tile t: issued together right after the barrier
+        // the eight waves' 32 pieces (32 KiB) queue on the CU's 64 B/clk L1 path and every wave stands in issue for hundreds of
+        // cycles before its first MFMA (measured: 1 800 cycles per K-tile against 512 of MFMA issue)
+        const bool dma = k0 + 2 * TDK < kend;
+        const int nbuf = buf == 0 ? 2 : buf - 1;
+        unsigned char* da = td_smem + nbuf * TD_STAGE + (2 * wave) * 1024;
+        unsigned char* db = da + TDK * 256;
+        const size_t ka = (size_t)(k0 + 2 * TDK) * lda, kb = (size_t)(k0 + 2 * TDK) * ldb;
         const unsigned char* st = td_smem + buf * TD_STAGE;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -994,10 +1003,21 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const bf16_t* __restri
                 b[f] = frag(st + ks * 16 * 256 + offb[f]);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (dma) {
+                    if (i == 0)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[s2] + ka),
+                                                         (__attribute__((address_space(3))) void*)(da + s2 * 1024), 16, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[s2] + kb),
+                                                         (__attribute__((address_space(3))) void*)(db + s2 * 1024), 16, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
         buf = buf == 2 ? 0 : buf + 1;
     }
