@@ -207,6 +207,24 @@ int spv_rfft_real(const void* x, void* y, int rows, int dim, int transpose, int 
 int spv_haar_dwt(const void* x, void* y, int batch, int tokens, int dim, int axis, int levels, int inverse,
                  int dtype, void* scratch, void* stream);
 
+/* ---- dropout seeds under HIP-graph replay ----------------------------------------------------------------
+ * The dropout masks of spectre.py:70-73 / vit.py:30-38 come from a counter hash of (seed, element); seeds are by-value kernel
+ * arguments, frozen when a graph is captured.  spv_set_seed_device_ptr(word) makes every dropout kernel add the 64-bit device
+ * word to its seed (NULL restores eager behaviour); spv_seed_advance(word, stream) steps it -- captured once per training step, so
+ * every replay draws fresh masks.  No reference counterpart (the reference is eager PyTorch). */
+int spv_set_seed_device_ptr(const void* seed_word);
+int spv_seed_advance(void* seed_word, void* stream);
+
+/* ---- AdamW over many tensors in one launch ------------------------------------------------------------
+ * The optimizer step the script drives: torch.optim.AdamW(lr, betas, weight_decay), spectre_vit/repl/train.py:199-201,237
+ * (decoupled weight decay, bias correction; amsgrad / maximize off).  `table`: device array of {float* p; const float* g;
+ * float* m; float* v;} per tensor; `sizes[t]` its element count; workgroup c updates elements [chunk_off[c], chunk_off[c] + 2048)
+ * of tensor chunk_tensor[c].  bias_correction1/2 = 1 - beta^step computed by the caller, or -- step_dev != NULL, for HIP-graph
+ * capture -- taken from the device-side step count *step_dev (already advanced for this step). */
+int spv_adamw_multi(const void* table, const int* chunk_tensor, const int* chunk_off, const int* sizes, int nchunks, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
+                    const float* step_dev, void* stream);
+
 /* ---- Walsh-Hadamard butterflies along the last axis -----------------------------------
  * spectre_vit/models/spectre/hadamar.py: fwht :12-32 / hadamard_transform :83-112 (mode 0, natural order; scale = n^-1/2
  * when normalised), fwht_fast :58-80 (mode 1: every stage interleaves sum / difference, un-normalised) and its transpose

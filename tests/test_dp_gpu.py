@@ -122,11 +122,11 @@ def test_bench_single_gpu_line_has_variants_and_cpu_baseline():
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SPV_BENCH_REHEARSAL"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--batch", "64", "--cpu-steps", "1", "--graph"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--batch", "64", "--cpu-steps", "1"]
     r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert rec["n_gpus"] == 1 and set(rec["variants"]) == {"permut", "dwt_embed"}
     assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["value"] > 0
     assert rec["roofline"]["bound"] in ("hbm", "mfma") and 0 < rec["roofline"]["frac"] < 1
-    assert rec["graph"]["graph_ms_per_step"] > 0
+    assert rec["graph"]["graph_ms_per_step"] == rec["ms_per_step"] > 0 and rec["eager"]["ms_per_step"] > 0  # headline = graph replay

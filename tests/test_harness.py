@@ -168,3 +168,84 @@ def test_config1_mnist_full_synthetic_epoch(tmp_path):
     # class-conditional synthetic images are learnable: one epoch must beat chance (1 %) by a wide margin
     assert hist[0]["Accuracy/Validation"] > 0.2, hist
     assert os.path.exists(os.path.join(tmp_path, "model_best.pt"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("capturable", [False, True])
+def test_fused_adamw_matches_torch_adamw_and_oracle(capturable):
+    """spectre_vit.optim.FusedAdamW (one HIP launch per step) against torch.optim.AdamW on identical parameters / gradients over
+    5 steps (tensors of awkward sizes: unaligned tails, a scalar), and its first step against the oracle's adamw_step
+    (reference optimizer call: train.py:199-201)."""
+    from oracle import spectre_oracle as O
+    from spectre_vit.optim import FusedAdamW
+    torch.manual_seed(0)
+    shapes = [(512, 768), (768,), (3,), (1,), (100, 512), (65, 512), (2049,), (4095,)]
+    a = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    oa = FusedAdamW(a, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, capturable=capturable)
+    ob = torch.optim.AdamW(b, lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+    p0 = a[0].detach().cpu().numpy().astype(np.float64)
+    for step in range(5):
+        grads = [torch.randn(s, device="cuda") * (0.1 + step) for s in shapes]
+        for t, g in zip(a, grads):
+            t.grad = g.clone()
+        for t, g in zip(b, grads):
+            t.grad = g.clone()
+        oa.step()
+        ob.step()
+        if step == 0:
+            ref, _, _ = O.adamw_step(p0, grads[0].cpu().numpy().astype(np.float64), np.zeros_like(p0), np.zeros_like(p0), 1)
+            assert np.abs(a[0].detach().cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+        for x, y in zip(a, b):
+            assert torch.allclose(x, y, rtol=2e-6, atol=2e-7), (step, x.shape, (x - y).abs().max().item())
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    assert set(sa[0].keys()) == set(sb[0].keys()) == {"step", "exp_avg", "exp_avg_sq"} and float(sa[0]["step"]) == 5.0
+    assert torch.allclose(sa[0]["exp_avg_sq"], sb[0]["exp_avg_sq"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_matches_eager_steps():
+    """spectre_vit.graph.GraphedTrainStep: three replays == three eager steps (same kernels, same order: bit for bit with dropout
+    off), and with dropout on every replay draws different masks (the device-side seed word advances inside the graph)."""
+    from spectre_vit.graph import GraphedTrainStep
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    from spectre_vit.optim import FusedAdamW
+    cfg = dict(img_size=32, patch_size=4, in_channels=3, num_classes=100, embed_dim=512, num_encoders=2, num_heads=16, hidden_dim=768,
+               activation="gelu")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(64, 3, 32, 32, generator=g).to(dev)
+    labels = torch.randint(0, 100, (64,), generator=g).to(dev)
+    crit = torch.nn.CrossEntropyLoss()
+
+    def make(dropout, capturable):
+        torch.manual_seed(11)
+        m = SpectreViT(**cfg, dropout=dropout, mixer="fft").to(dev).train()
+        return m, FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01, capturable=capturable)
+
+    m1, o1 = make(0.0, False)
+    eager_losses = []
+    for _ in range(3 + 3):  # GraphedTrainStep warms up with 3 real steps before it captures
+        o1.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m1(img)
+        loss = crit(out, labels)
+        loss.backward()
+        o1.step()
+        eager_losses.append(loss.item())
+    m2, o2 = make(0.0, True)
+    step = GraphedTrainStep(m2, o2, crit, img, labels, warmup=3)   # 3 warm-up steps + the captured (not executed) one
+    graph_losses = [step().item() for _ in range(3)]
+    step.close()
+    assert graph_losses == eager_losses[3:6], (graph_losses, eager_losses)
+    for (k, p), q in zip(m1.named_parameters(), m2.parameters()):
+        assert torch.equal(p, q), k
+    # dropout on: consecutive replays on the same batch and (frozen) weights differ only through the masks
+    m3, o3 = make(0.3, True)
+    for grp in o3.param_groups:
+        grp["lr"] = 0.0
+        grp["weight_decay"] = 0.0
+    step3 = GraphedTrainStep(m3, o3, crit, img, labels, warmup=1)
+    ls = [step3().item() for _ in range(4)]
+    step3.close()
+    assert len(set(ls)) == 4, ls

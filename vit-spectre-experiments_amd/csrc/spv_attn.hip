@@ -10,6 +10,7 @@
 // One wave per query row (forward, backward-1) or key row (backward-2): lanes over keys for the score row and the
 // softmax reductions, lanes over the head dimension for the P.V / dS.K products with the probabilities broadcast from
 // a wave-private LDS row.  v1 (below) is the general fallback; v2 (further down) stages the operands in LDS.
+#define SPV_USES_SEED
 #include "spv_common.h"
 
 namespace {
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const void* __restrict__ 
     }
     sum = wave_sum(sum);
     const float inv = 1.0f / sum, inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, i)) : 0u;
+    const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), attn_row(sh, len, i)) : 0u;
     const size_t prow_g = ((size_t)sh * len + i) * len;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const void* __restrict_
     for (int d = lane; d < hd; d += 64) grow[d] = ldq(dctx, gi + d, bf);
     lds_sync();
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, i)) : 0u;
+    const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), attn_row(sh, len, i)) : 0u;
     const size_t prow_g = ((size_t)sh * len + i) * len;
     float dp[MAXC], pr[MAXC];
     float dot = 0.0f;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const void* __restrict
     for (int i = lane; i < len; i += 64) {
         const size_t e = ((size_t)sh * len + i) * len + k;
         float p = ldq(probs, e, bf);
-        if (p_drop > 0.0f) p *= dropout_scale(dropout_row_key(seed, attn_row(sh, len, i)), (unsigned)k, p_drop, inv_keep);
+        if (p_drop > 0.0f) p *= dropout_scale(dropout_row_key(live_seed(seed), attn_row(sh, len, i)), (unsigned)k, p_drop, inv_keep);
         scol[i] = ldq(ds, e, bf);
         pcol[i] = p;
     }
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(64 * A2W) void attn2_fwd_kernel(const T* __restrict
         }
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
-        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, i)) : 0u;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), attn_row(sh, len, i)) : 0u;
         T* pg = probs + ((size_t)sh * len + i) * len;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c) {
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(64 * A2W) void attn2_bwd_q_kernel(const T* __restri
             const float4 t4 = *reinterpret_cast<const float4*>(grow + d);
             gv[d] = t4.x; gv[d + 1] = t4.y; gv[d + 2] = t4.z; gv[d + 3] = t4.w;
         }
-        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, i)) : 0u;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), attn_row(sh, len, i)) : 0u;
         const size_t pg = ((size_t)sh * len + i) * len;
         float dp[MAXC], pr[MAXC];
         float dot = 0.0f;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_kv_kernel(const T* __restrict__
         if (live) {
             pv = (float)io<T>::ld(probs + e);
             sv = (float)io<T>::ld(ds + e);
-            if (p_drop > 0.0f) pv *= dropout_scale(dropout_row_key(seed, attn_row(sh, len, i)), (unsigned)key, p_drop, inv_keep);
+            if (p_drop > 0.0f) pv *= dropout_scale(dropout_row_key(live_seed(seed), attn_row(sh, len, i)), (unsigned)key, p_drop, inv_keep);
         }
         const unsigned char* qr = Qs + (size_t)i * P::RS;
         const unsigned char* gr = Gs + (size_t)i * P::RS;
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? 4 : 3)) void attn3_fwd_kernel(cons
     const float inv = 1.0f / l;
     if (g == 0 && q < len) lse[(size_t)sh * len + q] = m + __logf(l);
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, qi)) : 0u;
+    const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), attn_row(sh, len, qi)) : 0u;
     f32x16 O[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d) O[d] = a3_zero();
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn3_bwd_q_kernel(co
     const float scale = rsqrtf((float)HD);
     const float lq = lse[(size_t)sh * len + qi];
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, attn_row(sh, len, qi)) : 0u;
+    const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), attn_row(sh, len, qi)) : 0u;
     const int nb = LR >> 5;
     float dot = 0.0f;
     f32x16 dQ[DB];
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(256, (HD == 32 ? 3 : 2)) void attn3_bwd_kv_kernel(c
         const bool ok = i < len;
         lse_s[i] = ok ? lse[(size_t)sh * len + i] : 0.0f;
         del_s[i] = ok ? delta[(size_t)sh * len + i] : 0.0f;
-        rk_s[i] = (ok && p_drop > 0.0f) ? dropout_row_key(seed, attn_row(sh, len, i)) : 0u;
+        rk_s[i] = (ok && p_drop > 0.0f) ? dropout_row_key(live_seed(seed), attn_row(sh, len, i)) : 0u;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, c = lane & 31;
@@ -940,3 +941,5 @@ extern "C" int spv_attention_bwd(const void* dctx, const void* qkv, const void* 
     SPV_LAUNCH_CHECK("spv_attention_bwd(kv)");
     return 0;
 }
+
+int spv_seed_ptr_set_attn(const unsigned long long* p) { return spv_seed_symbol_set(p); }

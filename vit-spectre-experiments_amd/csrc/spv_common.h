@@ -146,6 +146,18 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
+// HIP-graph replay: kernel arguments are frozen at capture time, so a dropout seed passed by value would repeat the captured
+// masks in every replay.  spv_set_seed_device_ptr() points every translation unit's g_seed_dev at one device word that the
+// caller advances once per step (inside the graph); each dropout kernel adds it to its by-value seed.  NULL (the default,
+// eager mode): seeds are used as passed.
+#ifdef SPV_USES_SEED
+__device__ const unsigned long long* g_seed_dev = nullptr;
+__device__ __forceinline__ uint64_t live_seed(uint64_t seed) { return g_seed_dev ? seed + *g_seed_dev : seed; }
+inline int spv_seed_symbol_set(const unsigned long long* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_seed_dev), &p, sizeof(p)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 __device__ __forceinline__ unsigned dropout_row_key(uint64_t seed, uint64_t row) {
     return mix32((unsigned)seed + (unsigned)row * 0x9e3779b1u) ^ mix32((unsigned)(seed >> 32) + (unsigned)(row >> 32));
 }

@@ -1,6 +1,7 @@
 // spv_patch.hip -- patch-embedding plumbing around the MFMA GEMM: pixel-block extraction, CLS/position rows,
 // the SpectralPatchEmbed weight fold (Re(rfft2 ortho) and the learnable frequency weights folded into the
 // projection matrix), dropout as a stand-alone counter-based mask.
+#define SPV_USES_SEED
 #include "spv_common.h"
 
 namespace {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ x
     const int64_t n8 = n >> 3;
     for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n8; v += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = v << 3;
-        const unsigned key = dropout_row_key(seed, (uint64_t)i >> 12);
+        const unsigned key = dropout_row_key(live_seed(seed), (uint64_t)i >> 12);
         const unsigned c0 = (unsigned)(i & 4095);
         float sc[8];
 #pragma unroll
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const void* __restrict__ x
     // ragged tail (n not a multiple of 8): scalar
     for (int64_t i = (n8 << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         st_any(y, (size_t)i, bf, ld_any(x, (size_t)i, bf) *
-                                     dropout_scale(dropout_row_key(seed, (uint64_t)i >> 12), (unsigned)(i & 4095), p, inv_keep));
+                                     dropout_scale(dropout_row_key(live_seed(seed), (uint64_t)i >> 12), (unsigned)(i & 4095), p, inv_keep));
 }
 
 __device__ __forceinline__ float rcoef(int u, int v, int p, int q, int P) {
@@ -262,3 +263,5 @@ extern "C" int spv_spectral_fold_bwd(const float* dw_full, const float* proj_w, 
     SPV_LAUNCH_CHECK("spv_spectral_fold_bwd(freq)");
     return 0;
 }
+
+int spv_seed_ptr_set_patch(const unsigned long long* p) { return spv_seed_symbol_set(p); }

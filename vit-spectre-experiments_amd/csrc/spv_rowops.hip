@@ -7,6 +7,7 @@
 // owns (registers in the generic kernels, per-wave LDS slots in the lane-contiguous ones), folded across
 // the 4 waves of a workgroup through LDS in a fixed order, written as one slab per workgroup and folded by
 // a second small kernel: deterministic, no atomics.
+#define SPV_USES_SEED
 #include "spv_common.h"
 
 namespace {
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(RT, (MAXI <= 4 ? 4 : (MAXI <= 12 ? 2 : 1))) void ta
         }
         float mean, rstd;
         row_stats<VEC, MAXI>(hv, n, lane, mean, rstd);
-        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), (uint64_t)row) : 0u;
         if (exact4) {
             // coalesced pass over the input row: lane sums 4 consecutive inputs; the owner of an output adds pw/4 of them
             lds_fence();
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(RT, (MAXI <= 4 ? 4 : (MAXI <= 12 ? 2 : 1))) void ta
 
     for (int row = wave_g; row < rows; row += nwaves) {
         const float mean = mean_i[row], rstd = rstd_i[row];
-        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), (uint64_t)row) : 0u;
         float xh[MAXI][VEC], dxh[MAXI][VEC];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
 #pragma unroll
         for (int c = 0; c < CO; ++c) { const float d = hv[c] - mean; q += d * d; }
         const float rstd = rsqrtf(wave_sum(q) / (float)n + LN_EPS);
-        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), (uint64_t)row) : 0u;
         const unsigned lane_gold = (unsigned)(lane * (CO / 2)) * 0x9e3779b1u;  // this lane's first column pair in the mask hash
         float o[CO];
 #pragma unroll
@@ -717,7 +718,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
     for (int i = 0; i < NP * Q; ++i) accw[i * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (int row = wave_g; row < rows; row += nwaves) {
         const float mean = mean_i[row], rstd = rstd_i[row];
-        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed, (uint64_t)row) : 0u;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), (uint64_t)row) : 0u;
         const unsigned lane_gold = (unsigned)(lane * (CO / 2)) * 0x9e3779b1u;  // this lane's first column pair in the mask hash
         float hv[CO], dv[CO], dxh[CO];
         if (LN2) {
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
                 float u[CI];
                 ld_span<CI>(up.src, (size_t)row * k_in + lane * CI, bf, u);
                 if (up.p_drop > 0.0f) {
-                    const unsigned ukey = dropout_row_key(up.seed, (uint64_t)row);
+                    const unsigned ukey = dropout_row_key(live_seed(up.seed), (uint64_t)row);
                     const float uinv = 1.0f / (1.0f - up.p_drop);
 #pragma unroll
                     for (int c = 0; c < CI; ++c) u[c] *= dropout_scale_at(ukey + (unsigned)(lane * (CI / 2)) * 0x9e3779b1u, c, up.p_drop, uinv);
@@ -1082,3 +1083,5 @@ extern "C" int spv_add_layernorm_bwd(const void* dout, const void* a, const void
     SPV_LAUNCH_CHECK("spv_add_layernorm_bwd(fold)");
     return 0;
 }
+
+int spv_seed_ptr_set_rowops(const unsigned long long* p) { return spv_seed_symbol_set(p); }

@@ -183,6 +183,8 @@ _WORK_MODELS = {
     # read dout and the pre-norm tensor, write dx
     "spv_fnet_ln_bwd": lambda i: ("fnet_ln_bwd", i[0:3], i[3], "hbm", 3.0 * i[0] * i[1] * i[2] * _es(i[3])),
     "spv_haar_dwt": lambda i: ("haar_dwt", i[0:3], i[6], "hbm", 2.0 * i[0] * i[1] * i[2] * _es(i[6])),
+    # p, g, m, v read + p, m, v written, 2048 elements per workgroup (the last chunk of a tensor is short: an upper bound)
+    "spv_adamw_multi": lambda i: ("adamw_multi", i[0:1], F32, "hbm", 7.0 * 4 * 2048 * i[0]),
     "spv_weight_shadows": lambda i: ("weight_shadows", i[0:2], i[3], "hbm", i[0] * i[1] * (4.0 + 2 * _es(i[3]))),
     "spv_dropout": lambda i: ("dropout", i[0:1], i[1], "hbm", 2.0 * i[0] * _es(i[1])),
     "spv_axpby": lambda i: ("axpby", i[0:1], i[1], "hbm", 3.0 * i[0] * _es(i[1])),
