@@ -161,7 +161,7 @@ class Job:
         self.img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
         labels = torch.randint(0, 100, (args.batch,), generator=g).to(torch.uint8).to(dev)  # uint8 as train.py:218
         self.labels = labels.long()
-        self.reducer = GradReducer(model)
+        self.reducer = GradReducer(model, always=not stand_in)  # fixed gradient addresses (one-launch optimizer's pointer table)
         if stand_in or os.environ.get("SPV_TORCH_ADAMW") == "1":  # A/B aid: torch's own fused AdamW
             self.opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, fused=not stand_in)
         else:  # the same update rule on one launch (spectre_vit/optim.py; parity-tested against torch.optim.AdamW)

@@ -219,11 +219,12 @@ int spv_seed_advance(void* seed_word, void* stream);
  * The optimizer step the script drives: torch.optim.AdamW(lr, betas, weight_decay), spectre_vit/repl/train.py:199-201,237
  * (decoupled weight decay, bias correction; amsgrad / maximize off).  `table`: device array of {float* p; const float* g;
  * float* m; float* v;} per tensor; `sizes[t]` its element count; workgroup c updates elements [chunk_off[c], chunk_off[c] + 2048)
- * of tensor chunk_tensor[c].  bias_correction1/2 = 1 - beta^step computed by the caller, or -- step_dev != NULL, for HIP-graph
+ * of tensor chunk_tensor[c].  one_minus_beta1/2: 1 - beta rounded from double by the caller (torch forms them in double: 1 - 0.999
+ * taken in fp32 is off by 1.3e-5).  bias_correction1/2 = 1 - beta^step computed by the caller, or -- step_dev != NULL, for HIP-graph
  * capture -- taken from the device-side step count *step_dev (already advanced for this step). */
 int spv_adamw_multi(const void* table, const int* chunk_tensor, const int* chunk_off, const int* sizes, int nchunks, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
-                    const float* step_dev, void* stream);
+                    float beta1, float beta2, float one_minus_beta1, float one_minus_beta2, float eps, float weight_decay,
+                    float bias_correction1, float bias_correction2, const float* step_dev, void* stream);
 
 /* ---- Walsh-Hadamard butterflies along the last axis -----------------------------------
  * spectre_vit/models/spectre/hadamar.py: fwht :12-32 / hadamard_transform :83-112 (mode 0, natural order; scale = n^-1/2

@@ -315,8 +315,8 @@ struct AdamTensor { float* p; const float* g; float* m; float* v; };
 
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensor* __restrict__ tab, const int* __restrict__ chunk_tensor,
                                                           const int* __restrict__ chunk_off, const int* __restrict__ sizes, float lr,
-                                                          float beta1, float beta2, float eps, float wd, float bc1, float bc2,
-                                                          const float* __restrict__ step_dev) {
+                                                          float beta1, float beta2, float omb1, float omb2, float eps, float wd,
+                                                          float bc1, float bc2, const float* __restrict__ step_dev) {
     const int t = chunk_tensor[blockIdx.x];
     const int off = chunk_off[blockIdx.x];
     const AdamTensor a = tab[t];
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensor* __re
             float* pp = &p.x; float* mm = &m.x; float* vv = &v.x; const float* gg = &g.x;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                mm[u] = beta1 * mm[u] + (1.0f - beta1) * gg[u];
-                vv[u] = beta2 * vv[u] + (1.0f - beta2) * gg[u] * gg[u];
+                mm[u] = beta1 * mm[u] + omb1 * gg[u];
+                vv[u] = beta2 * vv[u] + omb2 * gg[u] * gg[u];
                 pp[u] = pp[u] * decay - step_size * mm[u] / (sqrtf(vv[u]) * inv_sqrt_bc2 + eps);
             }
             *reinterpret_cast<float4*>(a.p + i) = p;
@@ -351,8 +351,8 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensor* __re
                 const int j = i + u;
                 if (j >= n) break;
                 const float g = a.g[j];
-                const float m = beta1 * a.m[j] + (1.0f - beta1) * g;
-                const float v = beta2 * a.v[j] + (1.0f - beta2) * g * g;
+                const float m = beta1 * a.m[j] + omb1 * g;
+                const float v = beta2 * a.v[j] + omb2 * g * g;
                 a.m[j] = m;
                 a.v[j] = v;
                 a.p[j] = a.p[j] * decay - step_size * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
@@ -363,15 +363,15 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const AdamTensor* __re
 }  // namespace
 
 extern "C" int spv_adamw_multi(const void* table, const int* chunk_tensor, const int* chunk_off, const int* sizes, int nchunks, float lr,
-                               float beta1, float beta2, float eps, float weight_decay, float bias_correction1, float bias_correction2,
-                               const float* step_dev, void* stream) {
+                               float beta1, float beta2, float one_minus_beta1, float one_minus_beta2, float eps, float weight_decay,
+                               float bias_correction1, float bias_correction2, const float* step_dev, void* stream) {
     SPV_CHECK(nchunks >= 0, "spv_adamw_multi: nchunks = %d", nchunks);
     if (nchunks == 0) return 0;
     SPV_CHECK(table && chunk_tensor && chunk_off && sizes, "spv_adamw_multi: null table");
     SPV_CHECK(step_dev != nullptr || (bias_correction1 > 0.0f && bias_correction2 > 0.0f), "spv_adamw_multi: bias corrections must be > 0");
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const AdamTensor*>(table), chunk_tensor, chunk_off, sizes, lr, beta1, beta2, eps, weight_decay,
-                       bias_correction1, bias_correction2, step_dev);
+                       static_cast<const AdamTensor*>(table), chunk_tensor, chunk_off, sizes, lr, beta1, beta2, one_minus_beta1,
+                       one_minus_beta2, eps, weight_decay, bias_correction1, bias_correction2, step_dev);
     SPV_LAUNCH_CHECK("spv_adamw_multi");
     return 0;
 }

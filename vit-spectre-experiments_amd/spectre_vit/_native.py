@@ -71,7 +71,7 @@ SIGNATURES = {
     "spv_colsum": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "spv_set_seed_device_ptr": [c_vp],
     "spv_seed_advance": [c_vp, c_vp],
-    "spv_adamw_multi": [c_vp, c_vp, c_vp, c_vp, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_vp],
+    "spv_adamw_multi": [c_vp, c_vp, c_vp, c_vp, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_vp, c_vp],
     "spv_fwht": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_vp],
     "spv_axpby": [c_vp, c_vp, c_vp, c_f, c_f, c_i64, c_i, c_vp],
 }

@@ -25,7 +25,9 @@ RESERVED_CUS = 16  # CUs left to RCCL while gradients are exchanged during the b
 
 class GradReducer:
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 8.0, process_group=None, reduce_dtype=None,
-                 tail_mb: float = 2.0):
+                 tail_mb: float = 2.0, always: bool = False):
+        """always=True: lay the buckets out even in a single process (no exchange then): every gradient gets a FIXED address, which
+        a captured HIP graph and the one-launch optimizer's pointer table need (spectre_vit/graph.py, spectre_vit/optim.py)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -37,9 +39,9 @@ class GradReducer:
         self.adopted_numel = self.staged_numel = 0
         self.buckets = []  # dict(flat, params, pending, handle, stage)
         self._bucket_of = {}
-        if not self.params or self.world == 1:
+        if not self.params or (self.world == 1 and not always):
             return  # single process: no exchange, gradients stay ordinary per-parameter tensors
-        if self.params[0].is_cuda:
+        if self.params[0].is_cuda and self.world > 1:
             # the layer GEMMs run one workgroup per CU and cannot share a CU with a resident RCCL channel: leave 16 CUs to the
             # collectives that overlap the backward (free at the layer shapes, see spv.h: spv_set_reserved_cus)
             try:
@@ -122,7 +124,7 @@ class GradReducer:
             self.adopted_numel += p.numel()
         p.grad = v
         b["pending"] -= 1
-        if b["pending"] == 0:
+        if b["pending"] == 0 and self.world > 1:
             self._launch(b)
 
     def finish(self):

@@ -18,6 +18,7 @@ from __future__ import annotations
 import torch
 
 from spectre_vit import _native, hip_ops
+from spectre_vit.dp import GradReducer
 
 
 class GraphedTrainStep:
@@ -33,17 +34,20 @@ class GraphedTrainStep:
         self.img = example_img.clone()
         self.labels = example_labels.clone()
         dev = self.img.device
+        # fixed gradient addresses (the graph replays into them; the optimizer's pointer table is built once, before the capture)
+        self.reducer = GradReducer(model, always=True)
         self.seed_word = torch.zeros(1, dtype=torch.int64, device=dev)
         _native.call("spv_set_seed_device_ptr", self.seed_word.data_ptr())
         self._st = None
 
         def one_step():
             _native.call("spv_seed_advance", self.seed_word.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            self.optimizer.zero_grad(set_to_none=True)
+            self.reducer.zero_grad()
             with torch.autocast("cuda", dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
                 out = self.model(self.img)
             loss = self.criterion(out, self.labels)
             loss.backward()
+            self.reducer.finish()
             self.optimizer.step()
             return loss, out
 
@@ -56,7 +60,6 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         hip_ops._shadows = type(hip_ops._shadows)()  # the weight casts must be recorded in the graph, not served from a cache
         self.graph = torch.cuda.CUDAGraph()
-        self.optimizer.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self.loss, self.out = one_step()
 

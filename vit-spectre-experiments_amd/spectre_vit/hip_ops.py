@@ -285,6 +285,7 @@ def _gemm(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspa
 
 
 _SIDE_STREAM = os.environ.get("SPV_SIDE_STREAM", "1") != "0"
+_TN_DMA = os.environ.get("SPV_TN_DMA", "0") == "1"  # must match the library's own switch (spv_gemm.hip)
 _side_streams = {}
 _side_keep = []  # tensors a side-stream kernel still reads/writes: kept alive until the join
 
@@ -312,9 +313,9 @@ def _weight_grad(dh, x, rows, n, k, sink=None):
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
     # ~2 workgroups per CU: measured optimum on the 768 x 512 x 33280 weight gradient (21 splits: 51 us; 12: 69; 42: 56; 64: 64)
     splits = max(1, min(512 // tiles, (rows + 511) // 512 if tiles >= 8 else (rows + 63) // 64))
-    if n % 128 == 0 and k % 128 == 0 and rows % 64 == 0 and dh.dtype == torch.bfloat16:
-        # the LDS-DMA kernel (spv_gemm.hip gemm_tn_dma_kernel) runs ONE 9-wave workgroup per CU: one dispatch round of <= 256
-        # workgroups (24 tiles x 10 K-slices of 52 K-tiles at the layer shapes)
+    if _TN_DMA and n % 128 == 0 and k % 128 == 0 and rows % 64 == 0 and dh.dtype == torch.bfloat16:
+        # the LDS-DMA kernel (spv_gemm.hip gemm_tn_dma_kernel; opt-in, SPV_TN_DMA=1) runs ONE 8-wave workgroup per CU: one dispatch
+        # round of <= 256 workgroups (24 tiles x 10 K-slices of 52 K-tiles at the layer shapes)
         splits = max(1, min(256 // tiles, rows // 64))
     ws = None
     if dh.dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0:

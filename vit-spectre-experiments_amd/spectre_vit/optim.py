@@ -30,6 +30,10 @@ class FusedAdamW(torch.optim.Optimizer):
         t = self._tables.get(gi)
         if t is not None and t["key"] == key:
             return t
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("FusedAdamW: a parameter or gradient moved while a HIP graph is being captured (its pointer table "
+                               "cannot be uploaded inside a capture): give the gradients fixed addresses with "
+                               "spectre_vit.dp.GradReducer(model, always=True) and run a warm-up step first")
         dev = ps[0].device
         rows, ct, co, sizes = [], [], [], []
         for i, p in enumerate(ps):
@@ -43,10 +47,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 ct.append(i)
                 co.append(off)
         t = dict(key=key,
-                 table=torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True),
-                 chunk_tensor=torch.tensor(ct, dtype=torch.int32).to(dev, non_blocking=True),
-                 chunk_off=torch.tensor(co, dtype=torch.int32).to(dev, non_blocking=True),
-                 sizes=torch.tensor(sizes, dtype=torch.int32).to(dev, non_blocking=True), nchunks=len(ct),
+                 table=torch.tensor(rows, dtype=torch.int64).to(dev), chunk_tensor=torch.tensor(ct, dtype=torch.int32).to(dev),
+                 chunk_off=torch.tensor(co, dtype=torch.int32).to(dev), sizes=torch.tensor(sizes, dtype=torch.int32).to(dev),
+                 nchunks=len(ct),
                  step_dev=(self._tables.get(gi) or {}).get("step_dev"))
         self._tables[gi] = t
         return t
@@ -86,6 +89,6 @@ class FusedAdamW(torch.optim.Optimizer):
                 bc1, bc2 = 1.0 - b1 ** k, 1.0 - b2 ** k
                 step_ptr = 0
             _native.call("spv_adamw_multi", t["table"].data_ptr(), t["chunk_tensor"].data_ptr(), t["chunk_off"].data_ptr(),
-                         t["sizes"].data_ptr(), t["nchunks"], float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                         float(group["weight_decay"]), bc1, bc2, step_ptr, _stream())
+                         t["sizes"].data_ptr(), t["nchunks"], float(group["lr"]), float(b1), float(b2), 1.0 - b1, 1.0 - b2,
+                         float(group["eps"]), float(group["weight_decay"]), bc1, bc2, step_ptr, _stream())
         return loss
