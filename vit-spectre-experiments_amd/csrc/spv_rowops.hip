@@ -131,6 +131,7 @@ __global__ __launch_bounds__(RT, (MAXI <= 4 ? 4 : (MAXI <= 12 ? 2 : 1))) void ta
     const int wave_g = blockIdx.x * RW + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * RW;
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint64_t seed_l = live_seed(seed);  // hoisted: the graph-mode seed word is read once, not once per row
     for (int row = wave_g; row < rows; row += nwaves) {
         float hv[MAXI][VEC];
 #pragma unroll
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(RT, (MAXI <= 4 ? 4 : (MAXI <= 12 ? 2 : 1))) void ta
         }
         float mean, rstd;
         row_stats<VEC, MAXI>(hv, n, lane, mean, rstd);
-        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), (uint64_t)row) : 0u;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed_l, (uint64_t)row) : 0u;
         if (exact4) {
             // coalesced pass over the input row: lane sums 4 consecutive inputs; the owner of an output adds pw/4 of them
             lds_fence();
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(RT, (MAXI <= 4 ? 4 : (MAXI <= 12 ? 2 : 1))) void ta
     const int wave_g = blockIdx.x * RW + wave;
     const int nwaves = gridDim.x * RW;
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint64_t seed_l = live_seed(seed);  // hoisted: the graph-mode seed word is read once, not once per row
     float acc[3][MAXI][VEC];  // 0: dgamma, 1: dbeta, 2: dbias
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(RT, (MAXI <= 4 ? 4 : (MAXI <= 12 ? 2 : 1))) void ta
 
     for (int row = wave_g; row < rows; row += nwaves) {
         const float mean = mean_i[row], rstd = rstd_i[row];
-        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), (uint64_t)row) : 0u;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed_l, (uint64_t)row) : 0u;
         float xh[MAXI][VEC], dxh[MAXI][VEC];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -592,6 +594,35 @@ template <int CNT> __device__ __forceinline__ void st_span(void* base, size_t of
     }
 }
 
+// A lane's span as it lies in memory (packed bf16 pairs, or floats): loaded at the TOP of a row iteration, unpacked where it is
+// used -- so every load of the row is in flight at once, in half the registers floats would take.
+template <int CNT, int BF> struct RawSpan;
+template <int CNT> struct RawSpan<CNT, 1> { unsigned w[CNT / 2]; };
+template <int CNT> struct RawSpan<CNT, 0> { float w[CNT]; };
+template <int CNT, int BF> __device__ __forceinline__ void ld_raw(const void* base, size_t off, RawSpan<CNT, BF>& r) {
+    if constexpr (BF) {
+        const unsigned* p = reinterpret_cast<const unsigned*>(static_cast<const bf16_t*>(base) + off);
+#pragma unroll
+        for (int i = 0; i < CNT / 2; ++i) r.w[i] = p[i];
+    } else {
+        const float* p = static_cast<const float*>(base) + off;
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) r.w[i] = p[i];
+    }
+}
+template <int CNT, int BF> __device__ __forceinline__ void unpack(const RawSpan<CNT, BF>& r, float (&v)[CNT]) {
+    if constexpr (BF) {
+#pragma unroll
+        for (int i = 0; i < CNT / 2; ++i) {
+            v[2 * i] = __uint_as_float(r.w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(r.w[i] & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < CNT; ++i) v[i] = r.w[i];
+    }
+}
+
 // LayerNorm-2 of the encoder layer riding on the linear3 tail (reference spectre.py:67: norm2(x1 + ff(x1))): the tail's
 // output row f3 is complete in one wave, so x2 = LN2(x1 + f3) follows in registers (forward), and in the backward the
 // LayerNorm-2 gradient ds is formed in registers and used at once as the tail's incoming gradient.  Saves the
@@ -614,20 +645,31 @@ template <int CO, int CI, bool FASTG, bool LN2>
 __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restrict__ h, const void* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              void* __restrict__ out, float* __restrict__ mean_o,
-                                                             float* __restrict__ rstd_o, int rows, int bf, int out_bf, float p_drop,
+                                                             float* __restrict__ rstd_o, int rows, int bf_rt, int out_bf_rt, float p_drop,
                                                              uint64_t seed, TailLn2 ln) {
+    // the storage dtype is a COMPILE-TIME fact here (FASTG <=> bf16, and the host takes this kernel only when the output dtype
+    // matches): as run-time flags every 8-byte load sat in its own branch arm with its own s_waitcnt vmcnt(0) -- ten serialized
+    // memory round trips per row in the backward kernel, where one batch of loads is issued now
+    constexpr int bf = FASTG ? 1 : 0, out_bf = bf;
+    (void)bf_rt; (void)out_bf_rt;
     constexpr int n = 64 * CO, k_in = 64 * CI;
     const int lane = threadIdx.x & 63;
     const int wave_g = blockIdx.x * RW + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * RW;
     const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint64_t seed_l = live_seed(seed);  // hoisted: the graph-mode seed word is read once, not once per row
     float g[CO], b[CO];
     ld_span<CO>(gamma, (size_t)lane * CO, 0, g);
     ld_span<CO>(beta, (size_t)lane * CO, 0, b);
     for (int row = wave_g; row < rows; row += nwaves) {
+        RawSpan<CO, bf> r_h, r_res;
+        RawSpan<CI, bf> r_x;
+        ld_raw<CO, bf>(h, (size_t)row * n + lane * CO, r_h);
+        ld_raw<CI, bf>(x, (size_t)row * k_in + lane * CI, r_x);
+        if (LN2) ld_raw<CO, bf>(ln.res, (size_t)row * n + lane * CO, r_res);  // the residual of LayerNorm-2: asked for with the rest
         float hv[CO], xin[CI];
-        ld_span<CO>(h, (size_t)row * n + lane * CO, bf, hv);
-        ld_span<CI>(x, (size_t)row * k_in + lane * CI, bf, xin);
+        unpack<CO, bf>(r_h, hv);
+        unpack<CI, bf>(r_x, xin);
         float s = 0.0f;
 #pragma unroll
         for (int c = 0; c < CO; ++c) s += hv[c];
@@ -636,7 +678,7 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
 #pragma unroll
         for (int c = 0; c < CO; ++c) { const float d = hv[c] - mean; q += d * d; }
         const float rstd = rsqrtf(wave_sum(q) / (float)n + LN_EPS);
-        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), (uint64_t)row) : 0u;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed_l, (uint64_t)row) : 0u;
         const unsigned lane_gold = (unsigned)(lane * (CO / 2)) * 0x9e3779b1u;  // this lane's first column pair in the mask hash
         float o[CO];
 #pragma unroll
@@ -666,7 +708,7 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
         if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
         if (LN2) {
             float rv[CO], g2[CO], b2[CO];
-            ld_span<CO>(ln.res, (size_t)row * n + lane * CO, bf, rv);
+            unpack<CO, bf>(r_res, rv);
             float sm = 0.0f;
 #pragma unroll
             for (int c = 0; c < CO; ++c) { rv[c] += round_store(o[c], out_bf); sm += rv[c]; }  // x1 + f3 as the stored f3 reads back
@@ -703,9 +745,11 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
                                                              const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              void* __restrict__ dh, void* __restrict__ dxp, float* __restrict__ partials,
-                                                             int rows, int bf, int dout_bf, float p_drop, uint64_t seed,
+                                                             int rows, int bf_rt, int dout_bf_rt, float p_drop, uint64_t seed,
                                                              const void* __restrict__ dx_add, TailLn2 ln, TailUp up) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int bf = FASTG ? 1 : 0;  // compile-time dtype (dout has it too): see tail_fwd_lc_kernel
+    (void)bf_rt; (void)dout_bf_rt;
     constexpr int n = 64 * CO, k_in = 64 * CI, Q = CO / 4;
     constexpr int NP = LN2 ? 5 : 3;  // column-sum arrays: dgamma, dbeta, dbias (+ LayerNorm-2's dgamma, dbeta)
     static_assert(CO % 4 == 0, "lane span must be whole float4s");
@@ -716,17 +760,29 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
     float4* accw = reinterpret_cast<float4*>(lds) + (size_t)wave * NP * Q * 64 + lane;  // slot (p, q) at accw[(p*Q+q)*64]
 #pragma unroll
     for (int i = 0; i < NP * Q; ++i) accw[i * 64] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint64_t seed_l = live_seed(seed), up_seed_l = live_seed(up.seed);  // (one read of the graph-mode seed word, not one per row)
     for (int row = wave_g; row < rows; row += nwaves) {
+        // every load of the row goes out here, before the first use (they were issued -- and waited for -- one after the other)
+        RawSpan<CO, bf> r_h, r_d, r_s, r_t;
+        RawSpan<CI, bf> r_u, r_a;
+        ld_raw<CO, bf>(LN2 ? ln.dout2 : dout, (size_t)row * n + lane * CO, r_d);
+        ld_raw<CO, bf>(h, (size_t)row * n + lane * CO, r_h);
+        if (LN2) {
+            ld_raw<CO, bf>(ln.f3, (size_t)row * n + lane * CO, r_s);
+            ld_raw<CO, bf>(ln.res, (size_t)row * n + lane * CO, r_t);
+        }
+        if (!LN2 && up.src != nullptr) ld_raw<CI, bf>(up.src, (size_t)row * k_in + lane * CI, r_u);
+        if (dxp != nullptr && dx_add != nullptr) ld_raw<CI, bf>(dx_add, (size_t)row * k_in + lane * CI, r_a);
         const float mean = mean_i[row], rstd = rstd_i[row];
-        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(live_seed(seed), (uint64_t)row) : 0u;
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed_l, (uint64_t)row) : 0u;
         const unsigned lane_gold = (unsigned)(lane * (CO / 2)) * 0x9e3779b1u;  // this lane's first column pair in the mask hash
         float hv[CO], dv[CO], dxh[CO];
+        unpack<CO, bf>(r_d, dv);
         if (LN2) {
             // incoming gradient = LayerNorm-2 backward of dout2 at s = x1 + f3, formed here instead of by a separate kernel
             float sv[CO], tv[CO];
-            ld_span<CO>(ln.f3, (size_t)row * n + lane * CO, bf, sv);
-            ld_span<CO>(ln.res, (size_t)row * n + lane * CO, bf, tv);
-            ld_span<CO>(ln.dout2, (size_t)row * n + lane * CO, bf, dv);
+            unpack<CO, bf>(r_s, sv);
+            unpack<CO, bf>(r_t, tv);
             const float mean2 = ln.mean2[row], rstd2 = ln.rstd2[row];
             float t1 = 0.0f, t2 = 0.0f;
 #pragma unroll
@@ -755,14 +811,13 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
             for (int c = 0; c < CO; ++c) dv[c] = round_store(rstd2 * (tv[c] - n1 - sv[c] * n2), bf);
             st_span<CO>(ln.ds, (size_t)row * n + lane * CO, bf, dv);
         } else {
-            ld_span<CO>(dout, (size_t)row * n + lane * CO, dout_bf, dv);
             if (up.src != nullptr) {
                 // + the transposed pooling of the masked gradient of the layer above (its CI outputs per lane from its CO...
                 // seen from that layer: CI of its values, pooled onto CO of its inputs = this lane's CO columns)
                 float u[CI];
-                ld_span<CI>(up.src, (size_t)row * k_in + lane * CI, bf, u);
+                unpack<CI, bf>(r_u, u);
                 if (up.p_drop > 0.0f) {
-                    const unsigned ukey = dropout_row_key(live_seed(up.seed), (uint64_t)row);
+                    const unsigned ukey = dropout_row_key(up_seed_l, (uint64_t)row);
                     const float uinv = 1.0f / (1.0f - up.p_drop);
 #pragma unroll
                     for (int c = 0; c < CI; ++c) u[c] *= dropout_scale_at(ukey + (unsigned)(lane * (CI / 2)) * 0x9e3779b1u, c, up.p_drop, uinv);
@@ -777,7 +832,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
                 }
             }
         }
-        ld_span<CO>(h, (size_t)row * n + lane * CO, bf, hv);
+        unpack<CO, bf>(r_h, hv);
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -834,7 +889,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
         }
         if (dx_add != nullptr) {  // residual gradient folded in here instead of a separate elementwise add
             float ad[CI];
-            ld_span<CI>(dx_add, (size_t)row * k_in + lane * CI, bf, ad);
+            unpack<CI, bf>(r_a, ad);
 #pragma unroll
             for (int j = 0; j < CI; ++j) dx[j] += ad[j];
         }
@@ -919,7 +974,7 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
         const int fast = dtype == SPV_BF16, bfl = dtype == SPV_BF16, obf = out_dtype == SPV_BF16;
         dim3 lgrid(std::min(cdiv(rows, RW), 2048));
 #define LC_FWD(CO, CI)                                                                                                        \
-        if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
+        if (n == 64 * CO && k_in == 64 * CI && obf == bfl) {                                                                  \
             SPV_COUNT_PATH(SPV_PATH_TAIL_LC); \
             if (fast) hipLaunchKernelGGL((tail_fwd_lc_kernel<CO, CI, true, false>), lgrid, dim3(RT), 0, static_cast<hipStream_t>(stream), h, x, gamma, beta, out, mean, rstd, rows, bfl, obf, p_drop, seed, TailLn2{}); \
             else hipLaunchKernelGGL((tail_fwd_lc_kernel<CO, CI, false, false>), lgrid, dim3(RT), 0, static_cast<hipStream_t>(stream), h, x, gamma, beta, out, mean, rstd, rows, bfl, obf, p_drop, seed, TailLn2{});    \
@@ -955,7 +1010,8 @@ static int tail_bwd_impl(const void* dout, const void* h, const float* mean, con
         const int fast = dtype == SPV_BF16, bfl = dtype == SPV_BF16, dbf = dout_dtype == SPV_BF16;
         const int lwgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
 #define LC_BWD(CO, CI)                                                                                                        \
-        if (n == 64 * CO && k_in == 64 * CI) {                                                                                \
+        if (n == 64 * CO && k_in == 64 * CI && (dbf == bfl || up.src != nullptr)) {                                          \
+            SPV_CHECK(dbf == bfl, "spv_spectre_tail_bwd_up: dout must have the tensors' dtype");                              \
             hipStream_t lst = static_cast<hipStream_t>(stream);                                                               \
             SPV_COUNT_PATH(up.src ? SPV_PATH_TAIL_UP : SPV_PATH_TAIL_LC); \
             if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{}, up); \
