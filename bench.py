@@ -166,7 +166,7 @@ class Job:
             self.opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, fused=not stand_in)
         else:  # the same update rule on one launch (spectre_vit/optim.py; parity-tested against torch.optim.AdamW)
             from spectre_vit.optim import FusedAdamW
-            self.opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01)
+            self.opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, static_grads=True)
         self.crit = torch.nn.CrossEntropyLoss()
         self.use_bf16 = args.dtype == "bf16" and not stand_in
         self.dev = dev
@@ -211,7 +211,7 @@ def graph_replay(args, mixer, dev, steps, warmup):
     g = torch.Generator(device="cpu").manual_seed(1234)
     img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
     labels = torch.randint(0, 100, (args.batch,), generator=g).to(dev)
-    opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, capturable=True)
+    opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, capturable=True, static_grads=True)
     step = GraphedTrainStep(model, opt, torch.nn.CrossEntropyLoss(), img, labels,
                             autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     for _ in range(warmup):

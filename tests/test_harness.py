@@ -242,7 +242,9 @@ def test_graphed_train_step_matches_eager_steps():
     assert graph_losses[0] == eager_losses[3], (graph_losses, eager_losses)
     assert all(abs(a - b) <= 1e-4 * abs(b) for a, b in zip(graph_losses, eager_losses[3:6])), (graph_losses, eager_losses)
     for (k, p), q in zip(m1.named_parameters(), m2.parameters()):
-        assert torch.allclose(p, q, rtol=1e-3, atol=2e-5), (k, (p - q).abs().max().item())
+        # Adam's update m / (sqrt(v) + eps) is +-lr whatever the gradient's size, so one-ulp differences in tiny gradients move a
+        # weight by a fraction of an lr step (1e-3): the bound is 0.2 lr steps, not machine epsilon
+        assert torch.allclose(p, q, rtol=1e-3, atol=2e-4), (k, (p - q).abs().max().item())
     # dropout on: consecutive replays on the same batch and (frozen) weights differ only through the masks
     m3, o3 = make(0.3, True)
     for grp in o3.param_groups:

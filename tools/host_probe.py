@@ -23,8 +23,9 @@ def main():
     model = SpectreViT(**SMALL, mixer=mixer).to(dev).train()
     img = torch.randn(512, 3, 32, 32, device=dev)
     labels = torch.randint(0, 100, (512,), device=dev)
-    reducer = GradReducer(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+    from spectre_vit.optim import FusedAdamW
+    reducer = GradReducer(model, always=True)
+    opt = FusedAdamW(model.parameters(), lr=1e-3, static_grads=True)
     crit = torch.nn.CrossEntropyLoss()
 
     def step():

@@ -18,7 +18,14 @@ F32, BF16 = 0, 1
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """raw HIP handle of torch's current stream on the current device (the C getter: torch.cuda.current_stream() builds a Python
+    Stream object per call -- 10 us, 38 times per training step)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -285,6 +292,7 @@ def _gemm(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspa
 
 
 _SIDE_STREAM = os.environ.get("SPV_SIDE_STREAM", "1") != "0"
+_SIDE_MIN_FLOPS = float(os.environ.get("SPV_SIDE_MIN_FLOPS", "1e11"))  # weight gradients at least this big fork to the side stream
 _TN_DMA = os.environ.get("SPV_TN_DMA", "0") == "1"  # must match the library's own switch (spv_gemm.hip)
 _side_streams = {}
 _side_keep = []  # tensors a side-stream kernel still reads/writes: kept alive until the join
@@ -324,7 +332,7 @@ def _weight_grad(dh, x, rows, n, k, sink=None):
             if ws is None and splits > 1:
                 ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev)
             _native.call("spv_gemm_tn", _p(dh), _p(x), _p(dw), n, k, rows, n, k, k, F32, 0, splits, _p(ws), _stream())
-        if _SIDE_STREAM and not _timing() and 2.0 * rows * n * k >= 1e11:
+        if _SIDE_STREAM and not _timing() and 2.0 * rows * n * k >= _SIDE_MIN_FLOPS:
             # a big weight gradient (the MHPermutMix 8192 -> 512 linear: 279 GFLOP) has no consumer inside the backward
             # chain: run it on a second HIP stream so that it fills the ramp/tail gaps of the data-gradient GEMM and
             # overlaps the HBM-bound inverse gather on the main stream (10.57 -> 10.38 ms/step).  Not worth it for the
