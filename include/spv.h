@@ -42,6 +42,7 @@ enum {
     SPV_PATH_TAIL_LN = 5,        /* spv_spectre_tail_ln_fwd / _bwd */
     SPV_PATH_FNET_MFMA = 6,      /* fnet_mfma_kernel (bf16, dim 512) */
     SPV_PATH_GATHER_LDS = 7,     /* LDS-staged MHPermutMix gather */
+    SPV_PATH_GEMM_TN_WIDE = 9,   /* gemm_tn_wide_kernel (256 x 128 tile; M % 256 == 0, N % 128 == 0) */
     SPV_PATH_GEMM_TN_DMA = 8,    /* gemm_tn_dma_kernel (LDS-DMA ring; M, N % 128 == 0, K % 64 == 0) */
     SPV_PATH_COUNT = 16
 };

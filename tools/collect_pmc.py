@@ -27,14 +27,13 @@ def run_pass(counter, outdir, mixer):
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     f = glob.glob(os.path.join(outdir, "*", "*counter_collection.csv"))[0]
     agg = collections.defaultdict(list)
+    dur = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
-            agg[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
-    dur = collections.defaultdict(list)
-    for t in glob.glob(os.path.join(outdir, "*", "*kernel_trace.csv")):
-        for r in csv.DictReader(open(t)):
-            dur[(r["Kernel_Name"], int(r["Grid_Size"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)
-    return {k: (sum(v) / len(v), len(v), (sum(dur[k]) / len(dur[k]) if dur.get(k) else None)) for k, v in agg.items()}
+            key = (r["Kernel_Name"], int(r["Grid_Size"]))
+            agg[key].append(float(r["Counter_Value"]))
+            dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3)  # the counter rows carry the dispatch's stamps
+    return {k: (sum(v) / len(v), len(v), sum(dur[k]) / len(dur[k])) for k, v in agg.items()}
 
 
 def main():

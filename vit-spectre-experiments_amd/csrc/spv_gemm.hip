@@ -894,6 +894,108 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// TN contraction, WIDE tile: 256 (m) x 128 (n) per 8-wave workgroup (waves 4 x 2, 64 x 64 each), otherwise gemm_tn_kernel's
+// structure (register-staged tiles three K-tiles deep, one LDS buffer, transposing fragment reads).  The weight gradients of the
+// encoder layers (768 x 512 x 33 280) are bound by the L2 -> LDS path, not by MFMA issue: a 128 x 128 tile moves 32 KiB per
+// 2.1 MFLOP K-tile (400 MB per launch through a path that sustains ~14 TB/s chip-wide), the 256 x 128 tile 48 KiB per 4.2 MFLOP
+// (300 MB) at the same number of split-K slabs (12 tiles x 21 slices = one workgroup per CU).
+constexpr int TWM = 256;              // tile rows (m)
+constexpr int TWROWA = TWM * 2 + 64;  // LDS bytes per k row of the A tile: 576 = 64 mod 256, the four k rows of a read group land in disjoint banks
+
+template <typename TO>
+__global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
+                                                           float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc,
+                                                           int k_per_split, int accumulate, int tiles_n, int tiles_mn, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];  // max(A + B tiles = 57 344 B, epilogue 8 x 9 216 B)
+    unsigned char* sA = tw_smem;
+    unsigned char* sB = tw_smem + TBK * TWROWA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);  // whole K-slices per XCD (see gemm_tn_kernel)
+    const int split = lin / tiles_mn, tile = lin % tiles_mn;
+    const int m0 = (tile / tiles_n) * TWM, n0 = (tile % tiles_n) * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+
+    // staging map: A = 64 k rows x 32 chunks of 16 B -> 4 per thread (rows arow + 16 i); B = 64 x 16 chunks -> 2 per thread
+    const int arow = tid >> 5, ach = tid & 31, brow = tid >> 4, bch = tid & 15;
+    const bool a_ok = (m0 + ach * 8) < M, b_ok = (n0 + bch * 8) < N;
+    struct RegTile { uint4 a[4], b[2]; };
+    RegTile r0, r1, r2;
+    auto load_tile = [&](int k0, RegTile& r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + arow + 16 * i;
+            r.a[i] = (k < kend && a_ok) ? *reinterpret_cast<const uint4*>(A + (size_t)k * lda + m0 + ach * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + brow + 32 * i;
+            r.b[i] = (k < kend && b_ok) ? *reinterpret_cast<const uint4*>(B + (size_t)k * ldb + n0 + bch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](const RegTile& r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sA + (arow + 16 * i) * TWROWA + ach * 16) = r.a[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(sB + (brow + 32 * i) * TROWB + bch * 16) = r.b[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const unsigned char* fa0 = sA + (8 * (g >> 1) + q) * TWROWA + (16 * (g & 1) + 4 * pp) * 2 + (wm * 64) * 2;
+    const unsigned char* fb0 = sB + (8 * (g >> 1) + q) * TROWB + (16 * (g & 1) + 4 * pp) * 2 + (wn * 64) * 2;
+    using lds_ptr = s16x4 __attribute__((address_space(3)))*;
+    auto fragA = [&](const unsigned char* p) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * TWROWA));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto multiply = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < TBK / 16; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f] = fragA(fa0 + ks * 16 * TWROWA + f * 64);
+                b[f] = tr_frag(fb0 + ks * 16 * TROWB + f * 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto step = [&](int k0, RegTile& r) __attribute__((always_inline)) {
+        store_tile(r);
+        __syncthreads();
+        if (k0 + 3 * TBK < kend) load_tile(k0 + 3 * TBK, r);
+        multiply();
+        __syncthreads();
+    };
+
+    load_tile(kbeg, r0);
+    if (kbeg + TBK < kend) load_tile(kbeg + TBK, r1);
+    if (kbeg + 2 * TBK < kend) load_tile(kbeg + 2 * TBK, r2);
+    for (int k0 = kbeg; k0 < kend; k0 += 3 * TBK) {
+        step(k0, r0);
+        if (k0 + TBK < kend) step(k0 + TBK, r1);
+        if (k0 + 2 * TBK < kend) step(k0 + 2 * TBK, r2);
+    }
+    store_acc_tile<TO>(acc, tw_smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr, nullptr, 0, 0, wm * 64, wn * 64);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // TN contraction, LDS-DMA variant: the weight gradients of the encoder layers, dW[768 x 512] = dh^T . x over 33 280 rows
 // (backward of layers.py:86).  Same output tile (128 x 128) as gemm_tn_kernel, but
 //   * operands staged by global_load_lds_dwordx4 (no staging VGPRs, no ds_write) into a THREE-stage LDS ring of 64 k rows,
@@ -1284,6 +1386,7 @@ extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, 
     // opt-in (SPV_TN_DMA=1): isolated it is 3-6 % faster than the register-staged kernel (52.5 vs 54.5 us incl. the reduce), inside
     // the training step it measured SLOWER (68 vs 47 us per launch), so the register-staged kernel stays the default
     static const int use_dma = getenv("SPV_TN_DMA") ? atoi(getenv("SPV_TN_DMA")) : 0;
+    static const int use_wide = getenv("SPV_TN_WIDE") ? atoi(getenv("SPV_TN_WIDE")) : 1;
     if (use_dma && M % BM == 0 && N % BN == 0 && K % TDK == 0 && k_per_split % TDK == 0 && (ws != nullptr || ldc % 4 == 0)) {
         const int nwg = tiles_m * tiles_n * splits;
         if (out_dtype == SPV_BF16) {
@@ -1297,6 +1400,23 @@ extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, 
         }
         SPV_LAUNCH_CHECK("spv_gemm_tn(dma)");
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN_DMA);
+    } else if (use_wide && splits >= 4 && M % TWM == 0 && N % BN == 0 && (M / TWM) * tiles_n * splits >= 128) {
+        // the 256 x 128 tile (8 waves, one workgroup per CU): the split-K layer weight gradients (SPV_TN_WIDE=0 for the 128 x 128
+        // kernel).  Measured in graph mode, alternating: 2.372 vs 2.385 ms/step -- 1.6 us per launch; without split-K (the MHPermutMix
+        // weight gradient, 512 x 8192 x 33 280) it is SLOWER (651 vs 510 us), hence splits >= 4
+        const int wt = (M / TWM) * tiles_n;
+        constexpr int WSMEM = 8 * 9216;
+        if (out_dtype == SPV_BF16) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, WSMEM);
+            hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t>), dim3(wt * splits), dim3(512), WSMEM, st, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C,
+                               ws, M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, wt, splits);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, WSMEM);
+            hipLaunchKernelGGL((gemm_tn_wide_kernel<float>), dim3(wt * splits), dim3(512), WSMEM, st, (const bf16_t*)A, (const bf16_t*)B, (float*)C, ws,
+                               M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, wt, splits);
+        }
+        SPV_LAUNCH_CHECK("spv_gemm_tn(wide)");
+        SPV_COUNT_PATH(SPV_PATH_GEMM_TN_WIDE);
     } else {
     dim3 grid(tiles_m * tiles_n * splits);
     static const int depth = getenv("SPV_TN_DEPTH") ? atoi(getenv("SPV_TN_DEPTH")) : 3;  // tuning aid: 1 = one K-tile in flight

@@ -291,6 +291,12 @@ def _gemm(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspa
                  _p(workspace), _stream())
 
 
+def _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspace=None):
+    """the raw C-ABI call (development tools time it directly)"""
+    _native.call("spv_gemm_nt", _p(a), _p(b), _p(bias), _p(c), M, N, K, lda, ldb, ldc, _dt(a), _dt(c), accumulate, splits,
+                 _p(workspace), _stream())
+
+
 _SIDE_STREAM = os.environ.get("SPV_SIDE_STREAM", "1") != "0"
 _SIDE_MIN_FLOPS = float(os.environ.get("SPV_SIDE_MIN_FLOPS", "1e11"))  # weight gradients at least this big fork to the side stream
 _TN_DMA = os.environ.get("SPV_TN_DMA", "0") == "1"  # must match the library's own switch (spv_gemm.hip)
