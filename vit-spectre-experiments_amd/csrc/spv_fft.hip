@@ -597,20 +597,6 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
         }
     }
     V2_STAMP(4);
-    // the residual rows of phase D (forward: the mixer's own input; backward / plain: add_in) are requested here, all at once and two
-    // barriers early: the barriers below wait for LDS only (s_waitcnt lgkmcnt + s_barrier, not __syncthreads, whose fence would also
-    // wait for these loads), so the rows travel under the stage write (a load per loop trip was a memory round trip per row)
-    const bf16_t* resp = FUSE == 1 ? ln.res : add_in;
-    uint4 rv[V2IT];
-#pragma unroll
-    for (int i = 0; i < V2IT; ++i) rv[i] = make_uint4(0, 0, 0, 0);  // bf16 zeros (plain mixer call: nothing to add)
-    if (resp != nullptr) {
-#pragma unroll
-        for (int i = 0; i < V2IT; ++i) {
-            const int r = min(wave + 8 * i, N - 1);
-            rv[i] = *reinterpret_cast<const uint4*>(resp + base + (size_t)r * V2D + ch * 8);
-        }
-    }
     V2_STAMP(5);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every read of Z is done: its LDS becomes the Y stage (Y1 rows [0,nh1), Y2 rows [nh1, 2 nh1))
@@ -642,9 +628,30 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
         }
     }
     V2_STAMP(7);
+    // the residual rows of phase D (forward: the mixer's own input; backward / plain: add_in) are requested here, all at once, as
+    // soon as the accumulators are dead (asked for while they were live, the loads pushed the kernel over its 128 registers: 26-48
+    // spilled VGPRs = 54 MB of scratch traffic per launch).  The barrier below waits for LDS only (s_waitcnt lgkmcnt + s_barrier,
+    // not __syncthreads, whose fence would also wait for these loads); a load per loop trip was a memory round trip per row
+    const bf16_t* resp = FUSE == 1 ? ln.res : add_in;
+    // opaque copies of the sample's offset and this lane's chunk: the forward's residual IS the mixer input, so hipcc otherwise keeps
+    // phase A's nine 64-bit row addresses alive across phases B and C for these loads and the stores of phase D -- 26 spilled VGPRs,
+    // 54 MB of scratch traffic per launch (FETCH/WRITE_SIZE: 184 MB against 102 MB algorithmic)
+    size_t base_d = base;
+    int ch_d = ch, wave_d = wave;
+    asm volatile("" : "+s"(base_d), "+v"(ch_d), "+v"(wave_d));
+    uint4 rv[V2IT];
+#pragma unroll
+    for (int i = 0; i < V2IT; ++i) rv[i] = make_uint4(0, 0, 0, 0);  // bf16 zeros (plain mixer call: nothing to add)
+    if (resp != nullptr) {
+#pragma unroll
+        for (int i = 0; i < V2IT; ++i) {
+            const int r = min(wave_d + 8 * i, N - 1);
+            rv[i] = *reinterpret_cast<const uint4*>(resp + base_d + (size_t)r * V2D + ch_d * 8);
+        }
+    }
     float gg[8], bb[8];
     if (FUSE == 1) {
-        const int k0 = ch * 8;
+        const int k0 = ch_d * 8;
         const float4 g0 = *reinterpret_cast<const float4*>(ln.gamma + k0), g1 = *reinterpret_cast<const float4*>(ln.gamma + k0 + 4);
         const float4 b0 = *reinterpret_cast<const float4*>(ln.beta + k0), b1 = *reinterpret_cast<const float4*>(ln.beta + k0 + 4);
         gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
     // ---- D: combine mirrored halves, 8 consecutive frequencies per lane, 16-byte stores; row r = wave + 8 i is this wave's
 #pragma unroll
     for (int i = 0; i < V2IT; ++i) {
-        const int r = wave + 8 * i, k0 = ch * 8;
+        const int r = wave_d + 8 * i, k0 = ch_d * 8;
         if (r >= N) continue;
         const bool low = 2 * r <= N;           // r <= N / 2
         const int m = low ? r : N - r;
@@ -667,7 +674,7 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
         const unsigned fw[4] = {fv.x, fv.y, fv.z, fv.w};
         // the mirror partners of k0 .. k0 + 7 are D - k0, D - k0 - 1, ..., D - k0 - 7: element 0 of chunk (64 - ch) & 63, then elements
         // 7 .. 1 of chunk 63 - ch -- one 16-byte and one 2-byte LDS read instead of eight 2-byte ones with their index arithmetic
-        const uint4 mv = *reinterpret_cast<const uint4*>(mir + 8 * (63 - ch));
+        const uint4 mv = *reinterpret_cast<const uint4*>(mir + 8 * (63 - ch_d));
         const float mf[8] = {v2_ld(mir + ((V2D - k0) & (V2D - 1))), __uint_as_float(mv.w & 0xffff0000u), __uint_as_float(mv.w << 16),
                              __uint_as_float(mv.z & 0xffff0000u), __uint_as_float(mv.z << 16), __uint_as_float(mv.y & 0xffff0000u),
                              __uint_as_float(mv.y << 16), __uint_as_float(mv.x & 0xffff0000u)};
@@ -682,7 +689,7 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
                 const float a1 = __uint_as_float(fw[u] & 0xffff0000u) + mf[2 * u + 1];
                 o[u] = pack_bf16x2(a0, a1);
             }
-            *reinterpret_cast<uint4*>(ln.prenorm + base + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4*>(ln.prenorm + base_d + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
             float v[8];
             float sm = 0.0f;
 #pragma unroll
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
                 o[u] = pack_bf16x2(a0, a1);
             }
         }
-        *reinterpret_cast<uint4*>(y + base + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4*>(y + base_d + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
     V2_STAMP(9);
     V2_STAMP_RT(11);
