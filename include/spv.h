@@ -62,6 +62,10 @@ int spv_cast_transpose(const void* src, int src_dtype, void* dst, int dst_dtype,
  * copy in the compute dtype (plain may be NULL: fp32 reads the parameter itself) and the transposed copy [cols, ld >= rows]
  * for the data-gradient GEMM.  Rebuilt every training step: optimizers update parameters in place. */
 int spv_weight_shadows(const float* w, void* plain, void* transposed, int rows, int cols, int ld, int dtype, void* stream);
+/* The same for every weight of a model in one launch: `table` = device array of {const float* src; void* plain; void* transposed;
+ * int rows, cols, ld, pad;}; workgroup b serves the 32 x 64 tile (tile_x[b], tile_y[b]) of tensor tile_tensor[b]. */
+int spv_weight_shadows_multi(const void* table, const int* tile_tensor, const int* tile_x, const int* tile_y, int ntiles, int dtype,
+                             void* stream);
 
 /* ---- dense contraction: C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) (+ C) ------------------------
  * nn.Linear inside SpectreLinear (spectre_vit/models/spectre/layers.py:85-86,100), its data and

@@ -67,11 +67,10 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const TI* __restric
 // transposed copy [cols, ld] (zero beyond rows) -- the two operand layouts the NT GEMMs read.  Run once per weight per
 // training step (the copies cannot be cached: see hip_ops._ShadowCache).
 template <typename TO>
-__global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restrict__ src, TO* __restrict__ plain, TO* __restrict__ tr,
-                                                            int rows, int cols, int ld) {
+__device__ __forceinline__ void weight_shadow_tile(const float* __restrict__ src, TO* __restrict__ plain, TO* __restrict__ tr, int rows,
+                                                   int cols, int ld, int bx, int by, float (*tile)[65]) {
     // 32 (rows) x 64 (cols) tile: 16-byte loads along the columns, the transposed copy leaves as 8 consecutive rows per thread
-    __shared__ float tile[32][65];
-    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 64;
+    const int r0 = by * 32, c0 = bx * 64;
     const int t = threadIdx.x;
     const bool vec = (cols & 3) == 0;
 #pragma unroll
@@ -111,6 +110,25 @@ __global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restr
                 if (r0 + r8 + u < ld) io<TO>::st(o + u, tile[r8 + u][cl]);
         }
     }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void weight_shadow_kernel(const float* __restrict__ src, TO* __restrict__ plain, TO* __restrict__ tr,
+                                                            int rows, int cols, int ld) {
+    __shared__ float tile[32][65];
+    weight_shadow_tile<TO>(src, plain, tr, rows, cols, ld, blockIdx.x, blockIdx.y, tile);
+}
+
+// every weight of the model in ONE launch (8 launches of 4.9 us each per training step otherwise): workgroup b serves tile
+// (tile_x[b], tile_y[b]) of tensor tile_tensor[b]
+struct ShadowTensor { const float* src; void* plain; void* tr; int rows, cols, ld, pad; };
+template <typename TO>
+__global__ __launch_bounds__(256) void weight_shadow_multi_kernel(const ShadowTensor* __restrict__ tab, const int* __restrict__ tile_tensor,
+                                                                  const int* __restrict__ tile_x, const int* __restrict__ tile_y) {
+    __shared__ float tile[32][65];
+    const ShadowTensor t = tab[tile_tensor[blockIdx.x]];
+    weight_shadow_tile<TO>(t.src, static_cast<TO*>(t.plain), static_cast<TO*>(t.tr), t.rows, t.cols, t.ld, tile_x[blockIdx.x],
+                           tile_y[blockIdx.x], tile);
 }
 
 template <typename T>
@@ -231,6 +249,24 @@ extern "C" int spv_cast_transpose(const void* src, int sd, void* dst, int dd, in
     else
         return spv_set_error("spv_cast_transpose: bad dtypes %d -> %d", sd, dd);
     SPV_LAUNCH_CHECK("spv_cast_transpose");
+    return 0;
+}
+
+extern "C" int spv_weight_shadows_multi(const void* table, const int* tile_tensor, const int* tile_x, const int* tile_y, int ntiles,
+                                        int dtype, void* stream) {
+    SPV_CHECK(ntiles >= 0, "spv_weight_shadows_multi: ntiles = %d", ntiles);
+    if (ntiles == 0) return 0;
+    SPV_CHECK(table && tile_tensor && tile_x && tile_y, "spv_weight_shadows_multi: null table");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SPV_BF16)
+        hipLaunchKernelGGL((weight_shadow_multi_kernel<bf16_t>), dim3(ntiles), dim3(256), 0, st, static_cast<const ShadowTensor*>(table),
+                           tile_tensor, tile_x, tile_y);
+    else if (dtype == SPV_F32)
+        hipLaunchKernelGGL((weight_shadow_multi_kernel<float>), dim3(ntiles), dim3(256), 0, st, static_cast<const ShadowTensor*>(table),
+                           tile_tensor, tile_x, tile_y);
+    else
+        return spv_set_error("spv_weight_shadows_multi: bad dtype %d", dtype);
+    SPV_LAUNCH_CHECK("spv_weight_shadows_multi");
     return 0;
 }
 

@@ -28,6 +28,7 @@ SIGNATURES = {
     "spv_cast": [c_vp, c_i, c_vp, c_i, c_i64, c_vp],
     "spv_cast_transpose": [c_vp, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_weight_shadows": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "spv_weight_shadows_multi": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "spv_gemm_nt": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "spv_gemm_nt_grouped_rows": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_set_reserved_cus": [c_i],

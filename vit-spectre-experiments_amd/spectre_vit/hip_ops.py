@@ -116,6 +116,7 @@ class _ShadowCache:
 
     def __init__(self):
         self._d = {}
+        self._fresh = {}
         self.epoch = 0
 
     def get(self, w: torch.Tensor, dtype: torch.dtype):
@@ -125,6 +126,10 @@ class _ShadowCache:
         training = torch.is_grad_enabled() and w.requires_grad
         if not training and ent is not None and ent[0]() is w and ent[1] == ver:
             return ent[2], ent[3]
+        fresh = self._fresh.pop(key, None)
+        # rebuilt for THIS forward by refresh_weight_shadows (one launch for all weights); void if an optimizer has stepped since
+        if fresh is not None and fresh[0]() is w and fresh[3] == (w._version, self.epoch):
+            return fresh[1], fresh[2]
         n, k = w.shape
         wd = w.detach()
         wc = wd if dtype == torch.float32 else torch.empty((n, k), dtype=dtype, device=w.device)
@@ -138,6 +143,60 @@ class _ShadowCache:
 
 
 _shadows = _ShadowCache()
+
+
+class ShadowSet:
+    """Persistent bf16 (W, W^T) copies of a fixed list of fp32 nn.Linear weights, rebuilt by ONE spv_weight_shadows_multi launch
+    per training forward (eight 4.9-us launches and sixteen allocations per step otherwise).  The copies are handed to the layers
+    through _ShadowCache.get, which consumes them once per weight and forward."""
+
+    def __init__(self, weights, dtype=torch.bfloat16):
+        self.weights = [weakref.ref(w) for w in weights]
+        self.dtype = dtype
+        self.key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
+        dev = weights[0].device
+        rows, tt, tx, ty = [], [], [], []
+        self.bufs = []
+        for i, w in enumerate(weights):
+            n, k = w.shape
+            ld = (n + 7) // 8 * 8
+            wc = torch.empty((n, k), dtype=dtype, device=dev)
+            wt = torch.empty((k, ld), dtype=dtype, device=dev)
+            self.bufs.append((wc, wt))
+            rows += [w.data_ptr(), wc.data_ptr(), wt.data_ptr(), n | (k << 32), ld]  # {src, plain, tr, (rows, cols), (ld, pad)}
+            for by in range((ld + 31) // 32):
+                for bx in range((k + 63) // 64):
+                    tt.append(i)
+                    tx.append(bx)
+                    ty.append(by)
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.tt = torch.tensor(tt, dtype=torch.int32).to(dev)
+        self.tx = torch.tensor(tx, dtype=torch.int32).to(dev)
+        self.ty = torch.tensor(ty, dtype=torch.int32).to(dev)
+        self.ntiles = len(tt)
+
+    def refresh(self):
+        _native.call("spv_weight_shadows_multi", self.table.data_ptr(), self.tt.data_ptr(), self.tx.data_ptr(), self.ty.data_ptr(),
+                     self.ntiles, _DT[self.dtype], _stream())
+        for wr, (wc, wt) in zip(self.weights, self.bufs):
+            w = wr()
+            if w is not None:
+                _shadows._fresh[(id(w), self.dtype)] = (wr, wc, wt, (w._version, _shadows.epoch))
+
+
+def refresh_weight_shadows(module, weights_fn):
+    """called at the top of a model's bf16 training forward: module._spv_shadow_set is (re)built when a weight moved or changed shape"""
+    weights = weights_fn()
+    if not weights:
+        return
+    ss = getattr(module, "_spv_shadow_set", None)
+    key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
+    if ss is None or ss.key != key:
+        if torch.cuda.is_current_stream_capturing():
+            return  # (tables cannot be uploaded inside a capture: the per-weight path serves this forward)
+        ss = ShadowSet(weights)
+        object.__setattr__(module, "_spv_shadow_set", ss)
+    ss.refresh()
 
 
 def invalidate_weight_shadows(*_args, **_kwargs):

@@ -145,7 +145,20 @@ class SpectreViT(nn.Module):
         self.mlp_head = nn.Sequential(SpectreLinear(embed_dim, num_classes))
         self.mlp_head[0].out_fp32 = True  # logits leave in fp32, as they do under stock autocast (LayerNorm output)
 
+    def _shadow_weights(self):
+        """the encoder's nn.Linear weights whose bf16 (W, W^T) copies the GEMMs read (rebuilt every training forward)"""
+        ws = []
+        for layer in self.encoder_blocks.layers:
+            for mod in layer.modules():
+                if isinstance(mod, SpectreLinear):
+                    w = mod.local_head[0].weight
+                    if w.requires_grad and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+                        ws.append(w)
+        return ws
+
     def forward(self, x, return_features=False):
+        if torch.is_grad_enabled() and x.is_cuda and torch.is_autocast_enabled("cuda"):
+            hip_ops.refresh_weight_shadows(self, self._shadow_weights)  # all layers' bf16 weight copies in one launch
         x = self.embeddings_block(x)
         x = self.encoder_blocks(x)
         cls_token = x[:, 0, :]
