@@ -771,6 +771,7 @@ class PatchEmbedFn(torch.autograd.Function):
         # bf16: the backward's TN weight-gradient GEMM reads the patch matrix as it lies here (3 MB), so keep it
         ctx.save_for_backward(None if u8 else img, patches if (dtype == torch.bfloat16 or u8) else None)
         ctx.meta = (B, C, H, W, patch, E, K, Np, T, dtype, cls.shape, pos.shape)
+        ctx.sinks = (_sink(bias), _sink(cls), _sink(pos))
         return tokens
 
     @staticmethod
@@ -781,11 +782,14 @@ class PatchEmbedFn(torch.autograd.Function):
         st = _stream()
         dtok = dtok.contiguous()
         part = torch.empty((min(B, 512) * T * E,), dtype=torch.float32, device=dev)
-        dpos = torch.empty((T, E), dtype=torch.float32, device=dev)
+        s_bias, s_cls, s_pos = ctx.sinks
+        dpos_full = _grad_buf(s_pos, pos_shape, dev)  # straight into the data-parallel bucket / the optimizer's fixed gradient slot
+        dpos = dpos_full.view(T, E)
         _native.call("spv_colsum", _p(dtok), _p(dpos), _p(part), B, T * E, _dt(dtok), st)
-        dbias = torch.empty((E,), dtype=torch.float32, device=dev)
+        dbias = _grad_buf(s_bias, (E,), dev)
         _native.call("spv_colsum", _p(dpos[1:]), _p(dbias), _p(part), T - 1, E, F32, st)
-        dcls = dpos[0].clone().reshape(cls_shape)
+        dcls = _grad_buf(s_cls, cls_shape, dev)
+        dcls.view(-1).copy_(dpos[0])
         if patches is not None and dtok.dtype == torch.bfloat16:
             # dW = dtok^T . P over all B*T token rows, with P the patch matrix widened by a zero row per image (the CLS
             # row): the TN kernel then takes dtok as it lies in memory -- no transposed copies of a 34 MB tensor
@@ -793,7 +797,7 @@ class PatchEmbedFn(torch.autograd.Function):
             pfull[:, 1:, :] = patches.view(B, Np, K)
             dwf = _weight_grad(dtok.view(B * T, E), pfull.view(B * T, K), B * T, E, K)
             join_side_stream()
-            return None, dwf, dbias, dcls, dpos.reshape(pos_shape), None, None, None
+            return None, dwf, dbias, dcls, dpos_full, None, None, None
         rows = B * Np
         ld = (rows + 7) // 8 * 8
         dyt = torch.empty((E, ld), dtype=dtok.dtype, device=dev)
@@ -808,7 +812,7 @@ class PatchEmbedFn(torch.autograd.Function):
         splits = max(1, min(1024 // tiles, (ld + 511) // 512))
         ws = torch.empty((splits * E * K,), dtype=torch.float32, device=dev) if splits > 1 else None
         _gemm(dyt, pt, None, dwf, E, K, ld, ld, ld, K, 0, splits, ws)
-        return None, dwf, dbias, dcls, dpos.reshape(pos_shape), None, None, None
+        return None, dwf, dbias, dcls, dpos_full, None, None, None
 
 
 # CIFAR-100 statistics of the reference loader (spectre_vit/repl/train.py:109-112)
@@ -887,6 +891,47 @@ class AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return g, g
+
+
+class TapClsFn(torch.autograd.Function):
+    """x -> (x, x[:, 0, :].copy): the encoder's global residual `output + src` (spectre.py:103) is consumed at the CLS row only
+    (spectre.py:198), so SpectreViT takes src's CLS row here, at the entrance of the layer stack.  src then has ONE consumer in the
+    autograd graph: its gradient is not accumulated from two full (B, N, E) tensors (a 102 MB torch add per step); the CLS row's
+    gradient is added in place to row 0 of the stack's input gradient instead."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        return x.view_as(x), x[:, 0, :].contiguous()
+
+    @staticmethod
+    def backward(ctx, gx, gcls):
+        if gcls is None:
+            return gx
+        if gx is None:
+            raise RuntimeError("TapClsFn: the layer stack produced no input gradient")
+        if not gx.is_contiguous():
+            gx = gx.contiguous()
+        gx[:, 0, :] += gcls.to(gx.dtype)  # in place: this edge owns the tensor (it was written for it by the first layer's backward)
+        return gx
+
+
+class ClsAddFn(torch.autograd.Function):
+    """(output, src_cls) -> output[:, 0, :] + src_cls: the only rows of `output + src` the model reads.  Backward hands the stack a
+    dense gradient that is zero off the CLS row (what slicing the full sum gave it before)."""
+
+    @staticmethod
+    def forward(ctx, out, src_cls):
+        _require_gpu(out, src_cls)
+        ctx.meta = (out.shape, out.dtype)
+        return out[:, 0, :] + src_cls
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype = ctx.meta
+        full = torch.zeros(shape, dtype=dtype, device=g.device)
+        full[:, 0, :] = g
+        return full, g
 
 
 # ------------------------------------------------------------------------------------------------

@@ -103,6 +103,17 @@ class SpectreEncoder(nn.Module):
             output = self.norm(output)
         return hip_ops.AddFn.apply(output, src)
 
+    def forward_cls(self, src: torch.Tensor):
+        """(forward(src))[:, 0, :] without forming the other rows of the global residual (SpectreViT reads nothing else,
+        reference spectre.py:198): same numbers, one (B, N, E) add and one gradient accumulation fewer per step."""
+        src = hip_ops.cast(src, hip_ops.compute_dtype(src))
+        output, src_cls = hip_ops.TapClsFn.apply(src)
+        for mod in self.layers:
+            output = mod(output)
+        if self.norm is not None:
+            output = self.norm(output)
+        return hip_ops.ClsAddFn.apply(output, src_cls)
+
 
 class SpectralPatchEmbed(nn.Module):
     """Per-patch Re(rfft2 ortho) * learnable frequency weights -> Linear -> CLS + position (+dropout)
@@ -160,8 +171,7 @@ class SpectreViT(nn.Module):
         if torch.is_grad_enabled() and x.is_cuda and torch.is_autocast_enabled("cuda"):
             hip_ops.refresh_weight_shadows(self, self._shadow_weights)  # all layers' bf16 weight copies in one launch
         x = self.embeddings_block(x)
-        x = self.encoder_blocks(x)
-        cls_token = x[:, 0, :]
+        cls_token = self.encoder_blocks.forward_cls(x)
         x = self.mlp_head(cls_token)
         if return_features:
             return x, cls_token
