@@ -833,27 +833,37 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
             }
         }
         unpack<CO, bf>(r_h, hv);
-        float s1 = 0.0f, s2 = 0.0f;
+        f32x2 s1v = {0.0f, 0.0f}, s2v = {0.0f, 0.0f};
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             float g[4], b[4], a0[4], a1[4];
             ld_span<4>(gamma, (size_t)lane * CO + 4 * q, 0, g);
             ld_span<4>(beta, (size_t)lane * CO + 4 * q, 0, b);
+            // column PAIRS on packed fp32 math (v_pk_*_f32): PMC showed this kernel VALU bound -- 569 vector instructions per row, the
+            // four waves of a SIMD asking for 120 % of its issue slots -- once its loads were batched
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; e += 2) {
                 const int c = 4 * q + e;
-                if (p_drop > 0.0f) dv[c] *= dropout_scale_at(rkey + lane_gold, c, p_drop, inv_keep);
-                const float xhat = (hv[c] - mean) * rstd;
-                float dgel, unused;
-                if (FASTG) gelu_fast(xhat * g[e] + b[e], unused, dgel);
-                else dgel = gelu_erf_grad(xhat * g[e] + b[e]);
-                const float dln = dv[c] * dgel;
-                a0[e] = dln * xhat;
-                a1[e] = dln;
-                const float t = dln * g[e];
-                dxh[c] = t;
-                s1 += t;
-                s2 += t * xhat;
+                if (p_drop > 0.0f) {
+                    dv[c] *= dropout_scale_at(rkey + lane_gold, c, p_drop, inv_keep);
+                    dv[c + 1] *= dropout_scale_at(rkey + lane_gold, c + 1, p_drop, inv_keep);
+                }
+                const f32x2 hv2 = {hv[c], hv[c + 1]}, g2 = {g[e], g[e + 1]}, b2 = {b[e], b[e + 1]}, dv2 = {dv[c], dv[c + 1]};
+                const f32x2 xhat = (hv2 - mean) * rstd;
+                f32x2 dgel, unused;
+                if (FASTG) gelu_fast2(xhat * g2 + b2, unused, dgel);
+                else {
+                    const f32x2 pre = xhat * g2 + b2;
+                    dgel = f32x2{gelu_erf_grad(pre.x), gelu_erf_grad(pre.y)};
+                }
+                const f32x2 dln = dv2 * dgel;
+                const f32x2 ax = dln * xhat;
+                const f32x2 t = dln * g2;
+                s1v += t;
+                s2v += t * xhat;
+                a0[e] = ax.x; a0[e + 1] = ax.y;
+                a1[e] = dln.x; a1[e + 1] = dln.y;
+                dxh[c] = t.x; dxh[c + 1] = t.y;
             }
             float4 v0 = accw[(0 * Q + q) * 64], v1 = accw[(1 * Q + q) * 64];
             v0.x += a0[0]; v0.y += a0[1]; v0.z += a0[2]; v0.w += a0[3];
@@ -862,15 +872,18 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
             accw[(1 * Q + q) * 64] = v1;
             __builtin_amdgcn_sched_barrier(0);  // keep the chunks sequential: interleaving them only adds live registers
         }
-        const float m1 = wave_sum(s1) / (float)n, m2 = wave_sum(s2) / (float)n;
+        const float m1 = wave_sum(s1v.x + s1v.y) / (float)n, m2 = wave_sum(s2v.x + s2v.y) / (float)n;
         float o[CO];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             float4 v2 = accw[(2 * Q + q) * 64];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; e += 2) {
                 const int c = 4 * q + e;
-                o[c] = rstd * (dxh[c] - m1 - (hv[c] - mean) * rstd * m2);
+                const f32x2 hv2 = {hv[c], hv[c + 1]}, t2 = {dxh[c], dxh[c + 1]};
+                const f32x2 o2 = (t2 - m1 - (hv2 - mean) * (rstd * m2)) * rstd;
+                o[c] = o2.x;
+                o[c + 1] = o2.y;
             }
             v2.x += o[4 * q]; v2.y += o[4 * q + 1]; v2.z += o[4 * q + 2]; v2.w += o[4 * q + 3];
             accw[(2 * Q + q) * 64] = v2;
