@@ -167,7 +167,11 @@ int spv_add_layernorm_bwd(const void* dout, const void* a, const void* b, const 
  * from spv_permut_pack: bit31 = sign (1 => -1), bits 0..30 = source index.
  * backward: dx[b,i] = sum_h sign[h,inv_h(i)] * dg[b,h,inv_h(i)] (each perms[h] is a permutation:
  * no atomics, head by head in LDS). */
-/* idx: uint32 [2][heads][d] -- [0] forward table (perm | sign), [1] inverse table (inverse perm | sign). */
+/* idx: spv_permut_table_words(heads, d) uint32 words, opaque to the caller: the wide tables uint32 [2][heads][d] -- [0] forward
+ * (perm | sign), [1] inverse (inverse perm | sign) -- followed, when d <= 65 536 and d % 8 == 0, by their compact form (uint16
+ * indices + one sign bit per element) which the bf16 kernels read instead: every workgroup walks the whole table, so its
+ * width is L2 traffic. */
+int64_t spv_permut_table_words(int heads, int d);
 int spv_permut_pack(const int64_t* perms, const float* signs, uint32_t* idx, int heads, int d, void* stream);
 /* pooled (nullable, [batch, heads*d / pool_window]): the average of every pool_window consecutive gathered elements
  * (what the SpectreLinear skip needs), produced on the fly so the tail kernel does not re-read g. */

@@ -112,6 +112,18 @@ def main():
     hh = torch.randn(ROWS, F, device=dev).to(bf)
     cases.append(("cast_transpose 33280x768 bf16", lambda: _native.call("spv_cast_transpose", p(hh), 1, p(t1), 1, ROWS, F, ROWS, 0, 0, 0, st), ROWS * F * 4, None))
 
+    if "gather" in "".join(flt):
+        heads, d = 16, NTOK * E
+        perms = torch.stack([torch.randperm(d) for _ in range(heads)]).to(dev)
+        signs = (torch.randint(0, 2, (heads, d)) * 2 - 1).float().to(dev)
+        idx = H.permut_pack(perms, signs)
+        xg = torch.randn(B, d, device=dev).to(bf)
+        gg = torch.empty(B, heads * d, device=dev, dtype=bf)
+        pooled = torch.empty(B * NTOK, E, device=dev, dtype=bf)
+        dxg = torch.empty_like(xg)
+        cases.append(("gather_fwd (+pooled skip)", lambda: _native.call("spv_permut_gather_fwd", p(xg), p(idx), p(gg), p(pooled), 16, B, heads, d, 1, st), B * d * (1 + heads) * 2, None))
+        cases.append(("gather_bwd", lambda: _native.call("spv_permut_gather_bwd", p(gg), p(idx), p(dxg), B, heads, d, 1, st), B * d * (1 + heads) * 2, None))
+
     for name, fn, byt, flops in cases:
         if flt and not any(f in name for f in flt if f != "mix"):
             continue

@@ -9,12 +9,49 @@
 // d-element slice at a time) in LDS with coalesced 16-byte loads, then gathers from LDS (random 2/4-byte
 // LDS reads instead of random global reads) and writes the destination coalesced.  Rows too large for the
 // 160 KB LDS (Base/224: d = 151 296) gather straight from global memory (L2 resident per sample).
+//
+// Every workgroup walks the whole table of its direction, so at bs 512 the uint32 table (2.1 MB at the Small width) costs
+// 1.1 GB of L2 -> CU traffic per launch -- twice the bytes the gather itself writes.  When d <= 65 536 the pack step therefore
+// also emits a COMPACT form (16-bit indices + one sign bit per element, 2.125 bytes per element) and the bf16 kernels use it;
+// the forward kernel additionally serves TWO samples per workgroup from one pass over the table (their rows interleaved in LDS
+// as bf16 pairs, so one 4-byte LDS read fetches both), which halves the table traffic again.
 #include "spv_common.h"
 
 namespace {
 
 constexpr int PT = 1024;         // threads per workgroup
 constexpr int LDS_LIMIT = 150 * 1024;
+
+// compact tables exist iff every index fits 16 bits and head slices start on a sign-byte boundary
+inline bool compact_ok(int d) { return d <= 65536 && d % 8 == 0; }
+struct Compact {
+    const uint16_t *fwd16, *inv16;
+    const uint8_t *fwd_sg, *inv_sg;
+};
+inline Compact compact_of(const uint32_t* idx, int64_t total) {
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(idx + 2 * total);
+    Compact c;
+    c.fwd16 = reinterpret_cast<const uint16_t*>(base);
+    c.inv16 = c.fwd16 + total;
+    c.fwd_sg = base + 4 * total;
+    c.inv_sg = c.fwd_sg + total / 8;
+    return c;
+}
+
+// compact tables from the wide ones: thread per 8 elements
+__global__ __launch_bounds__(256) void permut_compact_kernel(const uint32_t* __restrict__ wide, uint16_t* __restrict__ c16,
+                                                             uint8_t* __restrict__ sg, int64_t octets) {
+    for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < octets; o += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t w = wide[o * 8 + k];
+            c16[o * 8 + k] = (uint16_t)(w & 0xffffu);
+            bits |= (w >> 31) << k;
+        }
+        sg[o] = (uint8_t)bits;
+    }
+}
 
 __global__ __launch_bounds__(256) void permut_pack_kernel(const int64_t* __restrict__ perms, const float* __restrict__ signs,
                                                           uint32_t* __restrict__ fwd, uint32_t* __restrict__ inv, int heads, int d) {
@@ -173,9 +210,148 @@ __global__ __launch_bounds__(256) void gather_bwd_global_kernel(const T* __restr
     }
 }
 
+// forward, compact table, two samples per workgroup (bf16): grid = ceil(batch / 2).  LDS word e = (x[b0][e], x[b0 + 1][e]).
+__global__ __launch_bounds__(PT) void gather_fwd_pair_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ idx16,
+                                                             const uint8_t* __restrict__ sg8, uint16_t* __restrict__ g, int heads,
+                                                             int d, bf16_t* __restrict__ pooled, int pw, int batch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* row = reinterpret_cast<uint32_t*>(smem);
+    const int b0 = blockIdx.x * 2;
+    const bool two = b0 + 1 < batch;
+    const uint4* x0 = reinterpret_cast<const uint4*>(x + (size_t)b0 * d);
+    const uint4* x1 = reinterpret_cast<const uint4*>(x + (size_t)(two ? b0 + 1 : b0) * d);
+    const int nv = d >> 3;
+    for (int v = threadIdx.x; v < nv; v += PT) {
+        const uint4 a = x0[v], c = x1[v];
+        uint4 lo, hi;
+        lo.x = __builtin_amdgcn_perm(c.x, a.x, 0x05040100u); lo.y = __builtin_amdgcn_perm(c.x, a.x, 0x07060302u);
+        lo.z = __builtin_amdgcn_perm(c.y, a.y, 0x05040100u); lo.w = __builtin_amdgcn_perm(c.y, a.y, 0x07060302u);
+        hi.x = __builtin_amdgcn_perm(c.z, a.z, 0x05040100u); hi.y = __builtin_amdgcn_perm(c.z, a.z, 0x07060302u);
+        hi.z = __builtin_amdgcn_perm(c.w, a.w, 0x05040100u); hi.w = __builtin_amdgcn_perm(c.w, a.w, 0x07060302u);
+        reinterpret_cast<uint4*>(row)[2 * v] = lo;
+        reinterpret_cast<uint4*>(row)[2 * v + 1] = hi;
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)heads * d;
+    const int t8 = (int)(total >> 3);
+    uint4* g0 = reinterpret_cast<uint4*>(g + (size_t)b0 * total);
+    uint4* g1 = reinterpret_cast<uint4*>(g + (size_t)(b0 + 1) * total);
+    const int gl = pw >> 3;  // lanes per pooling window: 1, 2 or 4 (host checks)
+    // FU octets per thread per trip, the next trip's table reads issued before this trip's gathers: one octet per trip is a
+    // chain of L2 latency -> LDS latency -> store, 65 times over (1 workgroup per CU: 128 VGPRs to spend)
+    constexpr int FU = 4;
+    const uint4* tab = reinterpret_cast<const uint4*>(idx16);
+    uint4 idn[FU];
+    uint32_t sgn[FU];
+#pragma unroll
+    for (int k = 0; k < FU; ++k) {
+        const int q = threadIdx.x + k * PT;
+        idn[k] = make_uint4(0, 0, 0, 0); sgn[k] = 0;
+        if (q < t8) { idn[k] = tab[q]; sgn[k] = sg8[q]; }
+    }
+    for (int q0 = threadIdx.x; q0 < t8; q0 += FU * PT) {
+        uint4 idc[FU];
+        uint32_t sgc[FU];
+#pragma unroll
+        for (int k = 0; k < FU; ++k) { idc[k] = idn[k]; sgc[k] = sgn[k]; }
+#pragma unroll
+        for (int k = 0; k < FU; ++k) {
+            const int q = q0 + (FU + k) * PT;
+            if (q < t8) { idn[k] = tab[q]; sgn[k] = sg8[q]; }
+        }
+#pragma unroll
+      for (int u = 0; u < FU; ++u) {
+        const int q = q0 + u * PT;
+        if (q >= t8) break;
+        const uint4 id = idc[u];
+        const uint32_t sg = sgc[u];
+        uint32_t w[8];
+        w[0] = row[id.x & 0xffffu]; w[1] = row[id.x >> 16];
+        w[2] = row[id.y & 0xffffu]; w[3] = row[id.y >> 16];
+        w[4] = row[id.z & 0xffffu]; w[5] = row[id.z >> 16];
+        w[6] = row[id.w & 0xffffu]; w[7] = row[id.w >> 16];
+        uint32_t o0[4], o1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t m = ((sg << (15 - 2 * k)) & 0x8000u) | ((sg << (30 - 2 * k)) & 0x80000000u);
+            o0[k] = __builtin_amdgcn_perm(w[2 * k + 1], w[2 * k], 0x05040100u) ^ m;
+            o1[k] = __builtin_amdgcn_perm(w[2 * k + 1], w[2 * k], 0x07060302u) ^ m;
+        }
+        g0[q] = make_uint4(o0[0], o0[1], o0[2], o0[3]);
+        if (two) g1[q] = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+        if (pooled != nullptr) {
+            // the SpectreLinear skip averages pw consecutive gathered elements (layers.py:93,101): this lane has 8 of them
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s0 += __uint_as_float(o0[k] << 16) + __uint_as_float(o0[k] & 0xffff0000u);
+                s1 += __uint_as_float(o1[k] << 16) + __uint_as_float(o1[k] & 0xffff0000u);
+            }
+            if (gl >= 2) { s0 += dpp_mov<0xB1>(s0); s1 += dpp_mov<0xB1>(s1); }   // quad_perm [1,0,3,2]
+            if (gl >= 4) { s0 += dpp_mov<0x4E>(s0); s1 += dpp_mov<0x4E>(s1); }   // quad_perm [2,3,0,1]
+            if ((q & (gl - 1)) == 0) {
+                const float inv = 1.0f / (float)pw;
+                const size_t pr = (size_t)(total / pw);
+                io<bf16_t>::st(pooled + (size_t)b0 * pr + q / gl, s0 * inv);
+                if (two) io<bf16_t>::st(pooled + (size_t)(b0 + 1) * pr + q / gl, s1 * inv);
+            }
+        }
+      }
+    }
+}
+
+// backward, compact table (bf16): grid = batch; thread owns elements i = (it*PT + tid)*8 .. +7, it < C_IT
+constexpr int C_IT = 5;  // d <= 8 * PT * C_IT = 40 960
+__global__ __launch_bounds__(PT) void gather_bwd_c16_kernel(const bf16_t* __restrict__ dg, const uint16_t* __restrict__ inv16,
+                                                            const uint8_t* __restrict__ sg8, bf16_t* __restrict__ dx, int heads, int d) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* slice = reinterpret_cast<uint16_t*>(smem);
+    const int b = blockIdx.x;
+    const int nv = d >> 3;
+    float acc[C_IT][8];
+#pragma unroll
+    for (int it = 0; it < C_IT; ++it)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[it][k] = 0.0f;
+    // (prefetching the next head's slice into registers costs 20 VGPRs, which drops the second co-resident workgroup: 133 -> 298 us)
+    for (int h = 0; h < heads; ++h) {
+        const uint4* src = reinterpret_cast<const uint4*>(dg + ((size_t)b * heads + h) * d);
+        __syncthreads();  // previous head's gathers are done before the slice is overwritten
+        for (int v = threadIdx.x; v < nv; v += PT) reinterpret_cast<uint4*>(slice)[v] = src[v];
+        __syncthreads();
+        const uint4* ih = reinterpret_cast<const uint4*>(inv16 + (size_t)h * d);
+        const uint8_t* sh = sg8 + (((size_t)h * d) >> 3);
+#pragma unroll
+        for (int it = 0; it < C_IT; ++it) {
+            const int o = it * PT + threadIdx.x;
+            if (o < nv) {
+                const uint4 id = ih[o];
+                const uint32_t sg = sh[o];
+                const uint32_t e[8] = {id.x & 0xffffu, id.x >> 16, id.y & 0xffffu, id.y >> 16,
+                                       id.z & 0xffffu, id.z >> 16, id.w & 0xffffu, id.w >> 16};
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    acc[it][k] += __uint_as_float(((uint32_t)slice[e[k]] << 16) ^ ((sg << (31 - k)) & 0x80000000u));
+            }
+        }
+    }
+    bf16_t* out = dx + (size_t)b * d;
+#pragma unroll
+    for (int it = 0; it < C_IT; ++it) {
+        const int o = it * PT + threadIdx.x;
+        if (o < nv) {
+            uint4 w;
+            w.x = pack_bf16x2(acc[it][0], acc[it][1]); w.y = pack_bf16x2(acc[it][2], acc[it][3]);
+            w.z = pack_bf16x2(acc[it][4], acc[it][5]); w.w = pack_bf16x2(acc[it][6], acc[it][7]);
+            reinterpret_cast<uint4*>(out)[o] = w;
+        }
+    }
+}
+
 }  // namespace
 
-// idx: uint32 [2][heads][d]: [0] = forward table, [1] = inverse table
+// idx: spv_permut_table_words(heads, d) uint32 words: [2][heads][d] wide tables ([0] forward, [1] inverse), then -- when
+// d <= 65 536 and d % 8 == 0 -- the compact tables: uint16 [2][heads][d] indices and uint8 [2][heads * d / 8] sign bits
 extern "C" int spv_permut_pack(const int64_t* perms, const float* signs, uint32_t* idx, int heads, int d, void* stream) {
     SPV_CHECK(heads > 0 && d > 0, "spv_permut_pack: empty");
     SPV_CHECK((int64_t)d < (1ll << 31), "spv_permut_pack: d too large");
@@ -184,7 +360,20 @@ extern "C" int spv_permut_pack(const int64_t* perms, const float* signs, uint32_
     hipLaunchKernelGGL(permut_pack_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, st, perms, signs,
                        idx, idx + total, heads, d);
     SPV_LAUNCH_CHECK("spv_permut_pack");
+    if (compact_ok(d)) {
+        const Compact c = compact_of(idx, total);
+        const int64_t octets = total / 8;
+        const dim3 cg((unsigned)std::min<int64_t>((octets + 255) / 256, 2048));
+        hipLaunchKernelGGL(permut_compact_kernel, cg, dim3(256), 0, st, idx, const_cast<uint16_t*>(c.fwd16), const_cast<uint8_t*>(c.fwd_sg), octets);
+        hipLaunchKernelGGL(permut_compact_kernel, cg, dim3(256), 0, st, idx + total, const_cast<uint16_t*>(c.inv16), const_cast<uint8_t*>(c.inv_sg), octets);
+        SPV_LAUNCH_CHECK("spv_permut_pack(compact)");
+    }
     return 0;
+}
+
+extern "C" int64_t spv_permut_table_words(int heads, int d) {
+    const int64_t total = (int64_t)heads * d;
+    return 2 * total + (compact_ok(d) ? total + (total / 4 + 3) / 4 : 0);
 }
 
 extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g, void* pooled, int pool_window, int batch,
@@ -201,7 +390,16 @@ extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g
                       (total / 4) % PT == 0,
                   "spv_permut_gather_fwd: unsupported pool window %d", pool_window);
     }
-    if (aligned && (size_t)d * es <= (size_t)LDS_LIMIT) {
+    static const bool wide_only = getenv("SPV_PERMUT_WIDE") != nullptr;  // A/B switch: the round-1 kernels
+    const int64_t total_e = (int64_t)heads * d;
+    if (!wide_only && dtype == SPV_BF16 && compact_ok(d) && (size_t)d * 4 <= (size_t)LDS_LIMIT &&
+        (pooled == nullptr || ((pool_window == 8 || pool_window == 16 || pool_window == 32) && (total_e / 8) % PT == 0))) {
+        const Compact c = compact_of(idx, total_e);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_pair_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        SPV_COUNT_PATH(SPV_PATH_GATHER_LDS);
+        hipLaunchKernelGGL(gather_fwd_pair_kernel, dim3((batch + 1) / 2), dim3(PT), (size_t)d * 4, st, (const uint16_t*)x, c.fwd16, c.fwd_sg,
+                           (uint16_t*)g, heads, d, (bf16_t*)pooled, pool_window, batch);
+    } else if (aligned && (size_t)d * es <= (size_t)LDS_LIMIT) {
         const size_t lds = (size_t)d * es;
         if (dtype == SPV_BF16) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
@@ -230,7 +428,12 @@ extern "C" int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* 
     const uint32_t* inv = idx + (size_t)heads * d;
     const size_t es = dtype == SPV_BF16 ? 2 : 4;
     const bool aligned = ((size_t)d * es) % 16 == 0 && d % 4 == 0;
-    if (aligned && (size_t)d * es <= (size_t)LDS_LIMIT && d <= 4 * PT * MAX_IT) {
+    static const bool wide_only = getenv("SPV_PERMUT_WIDE") != nullptr;
+    if (!wide_only && dtype == SPV_BF16 && compact_ok(d) && (size_t)d * 2 <= (size_t)LDS_LIMIT && d <= 8 * PT * C_IT) {
+        const Compact c = compact_of(idx, (int64_t)heads * d);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_bwd_c16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        hipLaunchKernelGGL(gather_bwd_c16_kernel, dim3(batch), dim3(PT), (size_t)d * 2, st, (const bf16_t*)dg, c.inv16, c.inv_sg, (bf16_t*)dx, heads, d);
+    } else if (aligned && (size_t)d * es <= (size_t)LDS_LIMIT && d <= 4 * PT * MAX_IT) {
         const size_t lds = (size_t)d * es;
         if (dtype == SPV_BF16) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_bwd_lds_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);

@@ -996,6 +996,7 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
         }
         LC_FWD(12, 8)
         LC_FWD(8, 12)
+        LC_FWD(8, 8)   // 512 -> 512, identity skip: the MHPermutMix linear with its skip pooled by the gather
 #undef LC_FWD
     }
     const int pm = pool_mode_of(n, k_in);
@@ -1022,8 +1023,10 @@ static int tail_bwd_impl(const void* dout, const void* h, const float* mean, con
     {
         const int fast = dtype == SPV_BF16, bfl = dtype == SPV_BF16, dbf = dout_dtype == SPV_BF16;
         const int lwgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
+        // no skip gradient asked for (the data-gradient GEMM adds it in its epilogue): the input width plays no part
+        const int k_lc = (dx_pool == nullptr && up.src == nullptr) ? n : k_in;
 #define LC_BWD(CO, CI)                                                                                                        \
-        if (n == 64 * CO && k_in == 64 * CI && (dbf == bfl || up.src != nullptr)) {                                          \
+        if (n == 64 * CO && k_lc == 64 * CI && (dbf == bfl || up.src != nullptr)) {                                          \
             SPV_CHECK(dbf == bfl, "spv_spectre_tail_bwd_up: dout must have the tensors' dtype");                              \
             hipStream_t lst = static_cast<hipStream_t>(stream);                                                               \
             SPV_COUNT_PATH(up.src ? SPV_PATH_TAIL_UP : SPV_PATH_TAIL_LC); \
@@ -1036,6 +1039,7 @@ static int tail_bwd_impl(const void* dout, const void* h, const float* mean, con
         }
         LC_BWD(12, 8)
         LC_BWD(8, 12)
+        LC_BWD(8, 8)
 #undef LC_BWD
     }
     const int pm = pool_mode_of(n, k_in);

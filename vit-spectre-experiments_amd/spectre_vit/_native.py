@@ -46,6 +46,7 @@ SIGNATURES = {
     "spv_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_add_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "spv_permut_table_words": [c_i, c_i],
     "spv_permut_gather_fwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_gemm_nt_pool_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_gather_bwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
@@ -77,7 +78,7 @@ SIGNATURES = {
     "spv_axpby": [c_vp, c_vp, c_vp, c_f, c_f, c_i64, c_i, c_vp],
 }
 _RESTYPES = {"spv_last_error": ctypes.c_char_p, "spv_path_count": ctypes.c_longlong, "spv_rowop_partial_floats": c_i64, "spv_fnet_workspace_floats": c_i64,
-             "spv_fnet_twiddle_floats": c_i64, "spv_tail_ln_partial_floats": c_i64}
+             "spv_fnet_twiddle_floats": c_i64, "spv_tail_ln_partial_floats": c_i64, "spv_permut_table_words": c_i64}
 _NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_tail_ln_supported", "spv_tail_up_supported"}
 
 _lib = None

@@ -589,7 +589,8 @@ def add_layernorm(a, b, gamma, beta, mode):
 def permut_pack(perms: torch.Tensor, signs: torch.Tensor) -> torch.Tensor:
     _require_gpu(perms, signs)
     heads, d = perms.shape
-    idx = torch.empty((2, heads, d), dtype=torch.int32, device=perms.device)
+    # opaque to the caller: wide uint32 tables [2][heads][d] + (when d fits 16 bits) the compact 16-bit / sign-bit tables
+    idx = torch.empty((_native.call("spv_permut_table_words", heads, d),), dtype=torch.int32, device=perms.device)
     _native.call("spv_permut_pack", _p(perms.contiguous()), _p(signs.contiguous().float()), _p(idx), heads, d, _stream())
     return idx
 
