@@ -474,12 +474,14 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
     const int n0 = strip * 256;
     const int nkt = K / 64;
 
-    const bf16_t* bsrc[4];
+    // DMA sources as 32-bit byte offsets from the (uniform) operand bases: the base + K offset stay in SGPRs, one VGPR per
+    // piece instead of a 64-bit address pair (the host checks that both operands span < 4 GiB)
+    uint32_t bsrc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int R = 8 * (wave * 4 + t) + (lane >> 3);
         const int c = (lane & 7) ^ ((R >> 1) & 7);    // the swizzle of gemm_nt_glds_kernel<., 128, .>
-        bsrc[t] = B + (size_t)(n0 + R) * ldb + c * 8;
+        bsrc[t] = (uint32_t)(((size_t)(n0 + R) * ldb + c * 8) * 2);
     }
     const int frow = lane & 31, fh = lane >> 5, swz = (frow >> 1) & 7;
     const int fa_off = (wm * 32 * MB + frow) * 128;
@@ -491,8 +493,8 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
     const float* bv = sbias + wn * 64 + (lane & 7) * 8;
     const float* bvx = sbias + wave * 32 + (lane & 3) * 8;
 
-    const bf16_t* asrc[MB];
-    const bf16_t* axsrc;
+    uint32_t asrc[MB];
+    uint32_t axsrc;
     int s_m0, s_mlim, s_take;
     bool s_extra;
     auto setup = [&]() {  // descriptors + DMA source pointers of the sub-tile that starts at block blk0
@@ -504,26 +506,28 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
         for (int t = 0; t < MB; ++t) {
             const int R = 8 * (wave * MB + t) + (lane >> 3);
             const int c = (lane & 7) ^ ((R >> 1) & 7);
-            asrc[t] = A + (size_t)min(s_m0 + R, M - 1) * lda + c * 8;
+            asrc[t] = (uint32_t)(((size_t)min(s_m0 + R, M - 1) * lda + c * 8) * 2);
         }
         const int R = TM + 8 * (wave & 3) + (lane >> 3);
         const int c = (lane & 7) ^ ((R >> 1) & 7);
-        axsrc = A + (size_t)min(s_m0 + R, M - 1) * lda + c * 8;
+        axsrc = (uint32_t)(((size_t)min(s_m0 + R, M - 1) * lda + c * 8) * 2);
         blk0 += s_take;
         cnt -= s_take;
     };
     // one 1-KiB LDS-DMA piece of a K-tile (compile-time index: MB A pieces, 4 B pieces, the extra block's piece)
     auto piece = [&](auto ptag, int buf, int k0) __attribute__((always_inline)) {
         constexpr int P = decltype(ptag)::value;
+        const unsigned char* abase = reinterpret_cast<const unsigned char*>(A + k0);
+        const unsigned char* bbase = reinterpret_cast<const unsigned char*>(B + k0);
         if constexpr (P < MB)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[P < MB ? P : 0] + k0),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase + asrc[P < MB ? P : 0]),
                                              (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (wave * MB + P) * 1024), 16, 0, 0);
         else if constexpr (P < MB + 4)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[P >= MB && P < MB + 4 ? P - MB : 0] + k0),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bbase + bsrc[P >= MB && P < MB + 4 ? P - MB : 0]),
                                              (__attribute__((address_space(3))) void*)(smem + buf * STAGE + (TM + 32) * 128 + (wave * 4 + P - MB) * 1024), 16, 0, 0);
         else if constexpr (P == MB + 4) {
             if (s_extra && wave < 4)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(axsrc + k0),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(abase + axsrc),
                                                  (__attribute__((address_space(3))) void*)(smem + buf * STAGE + TM * 128 + wave * 1024), 16, 0, 0);
         }
     };
@@ -610,6 +614,10 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
                 dma = true;
             }
             const unsigned char* sp = smem + (t & 1) * STAGE;
+            // (Requesting the fragments of k-step ks + 1 before the MFMAs of k-step ks -- two register sets, 0-9 spilled VGPRs at MB = 4 --
+            // measured bit-identical and not a microsecond faster: the LDS latency is already hidden by the SIMD's second wave.  With every
+            // A row reading row 0 (SPV_STRIP_LDA0, A always in cache) the K = 8192 shape goes 297 -> 249 us, 37.6 -> 44.9 % of peak: HBM
+            // latency against ONE K-tile of prefetch is a fifth of the loop's time, the rest is the CU's own L1 -> LDS -> MFMA chain.)
             auto kstep = [&](auto kstag) __attribute__((always_inline)) {
                 constexpr int ks = decltype(kstag)::value;
                 const int ch = ((ks * 2 + fh) ^ swz) * 16;
@@ -1272,7 +1280,8 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
         int mb, nstrips, groups, base, rem;
         const bool bc_ok = bc == nullptr || (bc_bf && !accumulate && bc_pw % 8 == 0 && N % bc_pw == 0);
-        if (splits == 1 && rg == 0 && bias2d == nullptr && bc_ok && ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+        const bool span32 = (size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldb * 2 < (1ull << 32);  // 32-bit DMA source offsets
+        if (splits == 1 && rg == 0 && bias2d == nullptr && bc_ok && span32 && ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
             (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 3) == 0) && strip_plan(M, N, K, mb, nstrips, groups, base, rem)) {
             const int nwg = groups * nstrips;
 #define SPV_STRIP(MBV, EPIV)                                                                                                \
@@ -1280,6 +1289,10 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
                        static_cast<const bf16_t*>(B), bias, static_cast<bf16_t*>(C), M, K, lda, ldb, ldc, nstrips, base, rem, nwg, \
                        static_cast<const bf16_t*>(bc), bc_pw, bc ? N / bc_pw : 0)
             static const int acc_mb = getenv("SPV_STRIP_ACC_MB") ? atoi(getenv("SPV_STRIP_ACC_MB")) : 0;  // tuning aid
+            // diagnosis only (wrong results): every A row reads row 0, i.e. A always hits in L2 -- separates "HBM latency x one K-tile of
+            // prefetch" from "L2 -> LDS rate" as the bound of the K loop
+            static const bool lda0 = getenv("SPV_STRIP_LDA0") != nullptr;
+            if (lda0) lda = 0;
             if (accumulate && acc_mb >= 2 && acc_mb <= 4) mb = acc_mb;
             SPV_COUNT_PATH(accumulate ? SPV_PATH_GEMM_STRIP_ACC : SPV_PATH_GEMM_STRIP);
             if (bc != nullptr) {

@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libspv_hip.so")
+# SPV_LIB_PATH: a second build of the same ABI, for A/B runs inside one GPU job (tools/); never a fallback
+LIB_PATH = os.environ.get("SPV_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "lib", "libspv_hip.so")
 
 c_vp, c_i, c_i64, c_u64, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
