@@ -167,7 +167,11 @@ class Job:
         else:  # the same update rule on one launch (spectre_vit/optim.py; parity-tested against torch.optim.AdamW)
             from spectre_vit.optim import FusedAdamW
             self.opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, static_grads=True)
-        self.crit = torch.nn.CrossEntropyLoss()
+        if stand_in:
+            self.crit = torch.nn.CrossEntropyLoss()
+        else:  # nn.CrossEntropyLoss() semantics on one launch each way (spectre_vit/loss.py; parity-tested against torch's)
+            from spectre_vit.loss import CrossEntropyLoss
+            self.crit = CrossEntropyLoss()
         self.use_bf16 = args.dtype == "bf16" and not stand_in
         self.dev = dev
         self.param_bytes = sum(p.numel() for p in model.parameters()) * 4
@@ -212,7 +216,8 @@ def graph_replay(args, mixer, dev, steps, warmup):
     img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
     labels = torch.randint(0, 100, (args.batch,), generator=g).to(dev)
     opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, capturable=True, static_grads=True)
-    step = GraphedTrainStep(model, opt, torch.nn.CrossEntropyLoss(), img, labels,
+    from spectre_vit.loss import CrossEntropyLoss
+    step = GraphedTrainStep(model, opt, CrossEntropyLoss(), img, labels,
                             autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
     for _ in range(warmup):
         step()

@@ -295,6 +295,33 @@ int spv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, 
 int spv_colsum(const void* x, float* out, float* partials, int rows, int n, int dtype, void* stream);
 int spv_axpby(const void* x, const void* y, void* out, float a, float b, int64_t n, int dtype, void* stream);
 
+/* ---- the classifier end of the step: SpectreLinear over a few rows, and mean cross-entropy -------------------------
+ * The class head  mlp_head = SpectreLinear(embed, classes)  (spectre_vit/models/spectre/spectre.py:190-192, applied to
+ * (x + src)[:, 0] :199-202) and  nn.CrossEntropyLoss()  (spectre_vit/repl/train.py:196,226).  For rows <= 4096,
+ * n <= 128, k <= 1024, n <= k (spv_small_sl_supported) the whole SpectreLinear -- x = xa[row*lda] (+ xb[row*ldb]),
+ * h = x W^T + b over the fp32 master weights, LayerNorm, exact-erf GELU, adaptive-average-pooled skip -- is ONE
+ * launch; its backward two (rows: dh, dx, partial column sums; weights: dW and the fold of dgamma/dbeta/dbias).
+ * out, h, xs (the summed input, fp32 [rows,k]), mean, rstd are written by the forward and read by the backward;
+ * partials: spv_small_sl_partial_floats(rows, n) floats; dtype = type of xa / xb / dx. */
+int spv_small_sl_supported(int rows, int n, int k);
+int64_t spv_small_sl_partial_floats(int rows, int n);
+int spv_small_sl_fwd(const void* xa, int64_t lda, const void* xb, int64_t ldb, const float* W, const float* bias,
+                     const float* gamma, const float* beta, float* out, float* h, float* xs, float* mean, float* rstd,
+                     int rows, int n, int k, int dtype, void* stream);
+int spv_small_sl_bwd(const float* dout, const float* h, const float* xs, const float* mean, const float* rstd,
+                     const float* W, const float* gamma, const float* beta, float* dh, void* dx, float* dW,
+                     float* dgamma, float* dbeta, float* dbias, float* partials, int rows, int n, int k, int dx_dtype,
+                     void* stream);
+/* loss = mean_r(logsumexp(logits[r]) - logits[r][labels[r]]) (fp32 logits [rows, classes], int64 labels; a label outside
+ * [0, classes) makes the loss NaN).  lse [rows] is kept for the backward: dlogits = (softmax - onehot) * grad_out[0] / rows.
+ * workspace: spv_cross_entropy_workspace_floats() floats, ZEROED ONCE by the caller (it holds an arrival counter that
+ * every launch re-arms); the sum over rows is taken in a fixed order. */
+int64_t spv_cross_entropy_workspace_floats(void);
+int spv_cross_entropy_fwd(const float* logits, const int64_t* labels, float* lse, float* loss, float* workspace, int rows,
+                          int classes, void* stream);
+int spv_cross_entropy_bwd(const float* logits, const int64_t* labels, const float* lse, const float* grad_out,
+                          float* dlogits, int rows, int classes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -673,3 +673,77 @@ def test_learnable_hadamard_golden(golden_hadamard, dim, blocks, dtype):
         check(y, g[key + ".y"], 2e-6, "y vs reference")
         check(x.grad, g[key + ".dx"], 2e-6, "dx vs reference")
     assert all(p.grad is None for p in m.params)
+
+
+# ------------------------------------------------------------------------------------------------ class head + cross-entropy
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,E,n", [(512, 3, 512, 100), (6, 2, 64, 10), (9, 5, 768, 100), (5, 1, 64, 64), (130, 2, 1024, 128)])
+def test_cls_head_vs_oracle(ops, dtype, B, N, E, n):
+    """ClsHeadFn: SpectreLinear((out + src)[:, 0]) (reference spectre.py:198-202, layers.py:95-101) in one launch over the fp32
+    master weights, vs the float64 oracle on the same (dtype-rounded) inputs.  The arithmetic is fp32 for both input dtypes."""
+    rng = np.random.default_rng(B * 13 + E + n)
+    out = q(rng.standard_normal((B, N, E)), dtype)
+    src = q(rng.standard_normal((B, E)), dtype)
+    W = q(rng.standard_normal((n, E)) / np.sqrt(E), torch.float32)
+    b, g, be = (q(rng.standard_normal(n) * 0.1, torch.float32), q(rng.random(n) + 0.5, torch.float32),
+                q(rng.standard_normal(n) * 0.1, torch.float32))
+    dy = q(rng.standard_normal((B, n)), torch.float32)
+    dfe = q(rng.standard_normal((B, E)), torch.float32)
+    x = out[:, 0, :] + src
+    y_ref, dx_ref, gr = sl_oracle(x, W, b, g, be, dy)
+    Out, Src = t(out, dtype).requires_grad_(True), t(src, dtype).requires_grad_(True)
+    Wt, bt, gt, bet = (t(v).requires_grad_(True) for v in (W, b, g, be))
+    logits, feats = ops.ClsHeadFn.apply(Out, Src, Wt, bt, gt, bet)
+    assert logits.dtype == torch.float32 and feats.dtype == torch.float32
+    (logits * t(dy)).sum().backward(retain_graph=True)
+    tol = 2e-5
+    check(logits, y_ref, tol, "logits")
+    check(feats, x, 1e-6, "features")
+    dtol = tol * 2 if dtype == torch.float32 else 8e-3   # dx leaves in the stack's dtype
+    check(Src.grad, dx_ref, dtol, "d src_cls")
+    check(Out.grad[:, 0, :], dx_ref, dtol, "d out[:, 0]")
+    assert N == 1 or float(Out.grad[:, 1:, :].abs().max()) == 0.0
+    check(Wt.grad, gr["weight"], tol * 2, "dW")
+    check(bt.grad, gr["bias"], tol * 2, "db")
+    check(gt.grad, gr["ln_weight"], tol * 2, "dgamma")
+    check(bet.grad, gr["ln_bias"], tol * 2, "dbeta")
+    # a gradient arriving on the features (distillation's feature loss) is added to the input gradient
+    Src.grad = None
+    Out.grad = None
+    (feats * t(dfe)).sum().backward()
+    check(Src.grad, dfe, 8e-3 if dtype == torch.bfloat16 else 1e-6, "d src_cls via features")
+
+
+@pytest.mark.parametrize("rows,C", [(512, 100), (7, 1000), (33, 3), (1, 10), (4096, 10)])
+def test_cross_entropy_vs_torch_and_oracle(ops, rows, C):
+    """spv_cross_entropy_fwd/bwd = nn.CrossEntropyLoss() (reference train.py:196,226): loss and dlogits vs torch's fp32 kernels and vs
+    the float64 oracle, with an upstream factor on the loss (the distillation step scales it by 0.75)."""
+    rng = np.random.default_rng(rows + C)
+    z = rng.standard_normal((rows, C)) * 3.0
+    y = rng.integers(0, C, rows)
+    Z = t(z).requires_grad_(True)
+    Y = torch.from_numpy(y).to(dev())
+    loss = ops.cross_entropy(Z, Y)
+    (loss * 0.75).backward()
+    Zr = t(z).requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(Zr, Y)
+    (ref * 0.75).backward()
+    l64, d64 = O.cross_entropy_fwd_bwd(n64(t(z)), y)
+    assert abs(loss.item() - l64) <= 2e-6 * abs(l64) + 1e-7, (loss.item(), l64)
+    assert abs(loss.item() - ref.item()) <= 2e-6 * abs(l64) + 1e-7
+    check(Z.grad, 0.75 * d64, 2e-6, "dlogits vs oracle")
+    check(Z.grad, n64(Zr.grad), 2e-6, "dlogits vs torch")
+    again = ops.cross_entropy(Z, Y)   # the arrival counter re-arms itself: same result on the next launch, bit for bit
+    assert again.item() == loss.item()
+
+
+def test_cross_entropy_module_contract():
+    from spectre_vit.loss import CrossEntropyLoss
+    with pytest.raises(NotImplementedError):
+        CrossEntropyLoss(label_smoothing=0.1)
+    crit = CrossEntropyLoss()
+    with pytest.raises(RuntimeError):
+        crit(torch.zeros(2, 3), torch.zeros(2, dtype=torch.long))
+    z = torch.randn(8, 5, device=dev())
+    bad = torch.full((8,), 7, device=dev())
+    assert torch.isnan(crit(z, bad))  # a label outside [0, classes) poisons the loss; it never reads out of bounds

@@ -1,0 +1,31 @@
+"""Ordered kernel list of ONE training step (names, durations, gaps) out of a rocprofv3 --kernel-trace csv.
+   rocprofv3 --kernel-trace -d out -o t --output-format csv -- python3 bench.py --eager --steps 6 --warmup 3 --no-cpu-baseline --variants none --no-roofline
+   python3 tools/step_trace.py out/.../t_kernel_trace.csv [step_index_from_end]"""
+import csv
+import sys
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    names = [r["Kernel_Name"] for r in rows]
+    # a step starts at the patchify kernel
+    starts = [i for i, n in enumerate(names) if "patchify" in n]
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    a, b = starts[-k - 1], starts[-k]
+    t0 = int(rows[a]["Start_Timestamp"])
+    prev_end = t0
+    busy = 0
+    for r in rows[a:b]:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        n = r["Kernel_Name"]
+        n = n.replace("(anonymous namespace)::", "").replace("void ", "").replace("at::native::", "")
+        print(f"{(s - t0) / 1e3:9.1f} us  +gap {(s - prev_end) / 1e3:6.1f}  dur {(e - s) / 1e3:7.1f}  {n[:110]}")
+        prev_end = max(prev_end, e)
+        busy += e - s
+    span = int(rows[b]["Start_Timestamp"]) - t0
+    print(f"step span {span / 1e3:.1f} us, kernels {b - a}, busy {busy / 1e3:.1f} us")
+
+
+if __name__ == "__main__":
+    main()

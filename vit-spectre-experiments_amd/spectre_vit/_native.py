@@ -48,6 +48,13 @@ SIGNATURES = {
     "spv_add_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "spv_permut_table_words": [c_i, c_i],
+    "spv_small_sl_supported": [c_i, c_i, c_i],
+    "spv_small_sl_partial_floats": [c_i, c_i],
+    "spv_small_sl_fwd": [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
+    "spv_small_sl_bwd": [c_vp] * 15 + [c_i, c_i, c_i, c_i, c_vp],
+    "spv_cross_entropy_workspace_floats": [],
+    "spv_cross_entropy_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "spv_cross_entropy_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "spv_permut_gather_fwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_gemm_nt_pool_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_gather_bwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
@@ -79,8 +86,9 @@ SIGNATURES = {
     "spv_axpby": [c_vp, c_vp, c_vp, c_f, c_f, c_i64, c_i, c_vp],
 }
 _RESTYPES = {"spv_last_error": ctypes.c_char_p, "spv_path_count": ctypes.c_longlong, "spv_rowop_partial_floats": c_i64, "spv_fnet_workspace_floats": c_i64,
-             "spv_fnet_twiddle_floats": c_i64, "spv_tail_ln_partial_floats": c_i64, "spv_permut_table_words": c_i64}
-_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_tail_ln_supported", "spv_tail_up_supported"}
+             "spv_fnet_twiddle_floats": c_i64, "spv_tail_ln_partial_floats": c_i64, "spv_permut_table_words": c_i64, "spv_small_sl_partial_floats": c_i64,
+             "spv_cross_entropy_workspace_floats": c_i64}
+_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_tail_ln_supported", "spv_tail_up_supported", "spv_small_sl_supported"}
 
 _lib = None
 # live kernel timing (bench.py's roofline pass): when set, every entry point that launches on a stream is bracketed with HIP

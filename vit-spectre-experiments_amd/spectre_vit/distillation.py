@@ -67,5 +67,9 @@ def distillation_loss(student_logits, teacher_logits, labels, T=2.0, soft_target
     soft_targets = nn.functional.softmax(teacher_logits / T, dim=-1)
     soft_prob = nn.functional.log_softmax(student_logits / T, dim=-1)
     soft = torch.sum(soft_targets * (soft_targets.log() - soft_prob)) / soft_prob.size(0) * (T ** 2)
-    ce = nn.functional.cross_entropy(student_logits, labels)
+    if student_logits.is_cuda and student_logits.dtype == torch.float32:
+        from . import hip_ops
+        ce = hip_ops.cross_entropy(student_logits, labels)  # one launch each way (csrc/spv_head.hip)
+    else:
+        ce = nn.functional.cross_entropy(student_logits, labels)
     return soft_target_loss_weight * soft + ce_loss_weight * ce, soft, ce

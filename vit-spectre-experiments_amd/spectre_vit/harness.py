@@ -25,6 +25,7 @@ from torch import nn, optim
 from spectre_vit.configs.parser import parse_config
 from spectre_vit.distillation import SyntheticTeacher, distillation_loss
 from spectre_vit.dp import GradReducer, broadcast_module
+from spectre_vit.loss import CrossEntropyLoss
 from spectre_vit.models.spectre.spectre import SpectreViT
 
 CIFAR_MEAN = (0.5071, 0.4867, 0.4408)  # train.py:109-112
@@ -97,7 +98,7 @@ def train(config_path, mixer="permut", epochs=1, steps_per_epoch=None, batch_siz
     batch_size = batch_size or c.batch_size
     train_set = SyntheticCifar(n_train, c, device, seed=seed)
     val_set = SyntheticCifar(n_val, c, device, seed=seed + 1)
-    criterion = nn.CrossEntropyLoss()
+    criterion = CrossEntropyLoss()  # nn.CrossEntropyLoss() of train.py:196 on the HIP path (spectre_vit/loss.py)
     optimizer = optim.AdamW(model.parameters(), betas=c.adam_betas, lr=lr, weight_decay=c.adam_weight_decay)  # train.py:199-201
     reducer = GradReducer(model)
     teacher = SyntheticTeacher(c.num_classes, 384, c.in_channels).to(device) if distill else None

@@ -225,6 +225,10 @@ def _es(dt):
 # entry point -> f(ints) -> (label, shape, dtype code, bound, algorithmic work per call: flops (mfma) or compulsory bytes (hbm)).
 # ints are the integer arguments of the C-ABI call in header order (include/spv.h).
 _WORK_MODELS = {
+    "spv_small_sl_fwd": lambda i: ("head_fwd", i[2:5], i[5], "mfma", 2.0 * i[2] * i[3] * i[4]),
+    "spv_small_sl_bwd": lambda i: ("head_bwd", i[0:3], i[3], "mfma", 4.0 * i[0] * i[1] * i[2]),
+    "spv_cross_entropy_fwd": lambda i: ("cross_entropy_fwd", i[0:2], F32, "hbm", i[0] * i[1] * 4.0),
+    "spv_cross_entropy_bwd": lambda i: ("cross_entropy_bwd", i[0:2], F32, "hbm", i[0] * i[1] * 8.0),
     "spv_gemm_nt": lambda i: ("gemm_acc" if i[8] else "gemm", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
     "spv_gemm_nt_grouped_rows": lambda i: ("gemm_grouped_rows", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
     "spv_gemm_nt_pool_bwd": lambda i: ("gemm_pool_bwd", i[1:4], i[7], "mfma", 2.0 * i[1] * i[2] * i[3]),
@@ -933,6 +937,113 @@ class ClsAddFn(torch.autograd.Function):
         full = torch.zeros(shape, dtype=dtype, device=g.device)
         full[:, 0, :] = g
         return full, g
+
+
+# ------------------------------------------------------------------------------------------------
+# the classifier end of the step: class head over the CLS rows + mean cross-entropy (csrc/spv_head.hip)
+# ------------------------------------------------------------------------------------------------
+def small_head_ok(rows: int, n: int, k: int) -> bool:
+    return bool(_native.call("spv_small_sl_supported", int(rows), int(n), int(k)))
+
+
+class ClsHeadFn(torch.autograd.Function):
+    """(output, src_cls, head parameters) -> (logits fp32, CLS features fp32): SpectreLinear((output + src)[:, 0]) of the reference
+    (spectre.py:198-202, layers.py:95-101) as ONE launch over the fp32 master weights; backward two launches.  The generic path
+    (ClsAddFn + cast + fp32 shadow + split-K GEMM + reduce + tail, and five launches more in the backward) costs the same
+    arithmetic 13 launches at their 4-6 us floor."""
+
+    @staticmethod
+    def forward(ctx, out, src_cls, weight, bias, gamma, beta):
+        _require_gpu(out, src_cls, weight)
+        B, N, E = out.shape
+        n = weight.shape[0]
+        if not out.is_contiguous():
+            out = out.contiguous()
+        src_cls = src_cls.contiguous()
+        if src_cls.dtype != out.dtype or weight.dtype != torch.float32 or not weight.is_contiguous():
+            raise ValueError("ClsHeadFn: src_cls must have the stack's dtype and the head weight must be contiguous fp32")
+        dev = out.device
+        logits = torch.empty((B, n), dtype=torch.float32, device=dev)
+        h = torch.empty((B, n), dtype=torch.float32, device=dev)
+        xs = torch.empty((B, E), dtype=torch.float32, device=dev)
+        mean = torch.empty((B,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((B,), dtype=torch.float32, device=dev)
+        _native.call("spv_small_sl_fwd", _p(out), N * E, _p(src_cls), E, _p(weight), _p(bias), _p(gamma), _p(beta), _p(logits), _p(h),
+                     _p(xs), _p(mean), _p(rstd), B, n, E, _dt(out), _stream())
+        ctx.save_for_backward(h, xs, mean, rstd, weight, gamma, beta)
+        ctx.meta = (out.shape, out.dtype)
+        ctx.sinks = (_sink(weight), _sink(bias), _sink(gamma), _sink(beta))
+        ctx.set_materialize_grads(False)
+        return logits, xs
+
+    @staticmethod
+    def backward(ctx, dlogits, dfeats):
+        h, xs, mean, rstd, weight, gamma, beta = ctx.saved_tensors
+        shape, dtype = ctx.meta
+        B, n = h.shape
+        E = xs.shape[1]
+        dev = h.device
+        if dlogits is None:
+            dlogits = torch.zeros_like(h)
+        dlogits = dlogits.contiguous().float()
+        s_w, s_b, s_g, s_be = ctx.sinks
+        dh = torch.empty_like(h)
+        dx = torch.empty((B, E), dtype=dtype, device=dev)
+        dw = _grad_buf(s_w, (n, E), dev)
+        dbias = _grad_buf(s_b, (n,), dev)
+        dgamma = _grad_buf(s_g, (n,), dev)
+        dbeta = _grad_buf(s_be, (n,), dev)
+        partials = torch.empty((_native.call("spv_small_sl_partial_floats", B, n),), dtype=torch.float32, device=dev)
+        _native.call("spv_small_sl_bwd", _p(dlogits), _p(h), _p(xs), _p(mean), _p(rstd), _p(weight), _p(gamma), _p(beta), _p(dh), _p(dx),
+                     _p(dw), _p(dgamma), _p(dbeta), _p(dbias), _p(partials), B, n, E, _DT[dtype], _stream())
+        if dfeats is not None:
+            dx = dx + dfeats.to(dx.dtype)
+        full = torch.zeros(shape, dtype=dtype, device=dev)  # the stack's gradient is dense: zero off the CLS row
+        full[:, 0, :] = dx
+        return full, dx, dw, dbias, dgamma, dbeta
+
+
+_ce_workspaces = {}
+
+
+def _ce_workspace(dev):
+    key = (dev.index, _stream())
+    ws = _ce_workspaces.get(key)
+    if ws is None:
+        ws = torch.zeros((_native.call("spv_cross_entropy_workspace_floats"),), dtype=torch.float32, device=dev)
+        _ce_workspaces[key] = ws
+    return ws
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() with its defaults (mean over rows; reference repl/train.py:196,226): one launch forward (row-wise
+    logsumexp, deterministic sum), one backward -- stock torch runs log_softmax, nll_loss, two fills and their two backwards."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        _require_gpu(logits, labels)
+        if logits.dim() != 2 or logits.dtype != torch.float32 or labels.dtype != torch.int64 or labels.shape != logits.shape[:1]:
+            raise ValueError("cross_entropy: fp32 logits [rows, classes] and int64 labels [rows] expected")
+        z = logits.contiguous()
+        y = labels.contiguous()
+        rows, C = z.shape
+        lse = torch.empty((rows,), dtype=torch.float32, device=z.device)
+        loss = torch.empty((), dtype=torch.float32, device=z.device)
+        _native.call("spv_cross_entropy_fwd", _p(z), _p(y), _p(lse), _p(loss), _p(_ce_workspace(z.device)), rows, C, _stream())
+        ctx.save_for_backward(z, y, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, go):
+        z, y, lse = ctx.saved_tensors
+        go = go.reshape(1).float().contiguous()
+        dz = torch.empty_like(z)
+        _native.call("spv_cross_entropy_bwd", _p(z), _p(y), _p(lse), _p(go), _p(dz), z.shape[0], z.shape[1], _stream())
+        return dz, None
+
+
+def cross_entropy(logits, labels):
+    return CrossEntropyFn.apply(logits, labels)
 
 
 # ------------------------------------------------------------------------------------------------

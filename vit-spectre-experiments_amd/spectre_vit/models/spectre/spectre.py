@@ -114,6 +114,17 @@ class SpectreEncoder(nn.Module):
             output = self.norm(output)
         return hip_ops.ClsAddFn.apply(output, src_cls)
 
+    def forward_cls_parts(self, src: torch.Tensor):
+        """forward_cls without the final CLS-row add: (stack output (B, N, E), CLS row of the stack input (B, E)) for a consumer
+        that folds the add into its own kernel (the class head, hip_ops.ClsHeadFn)."""
+        src = hip_ops.cast(src, hip_ops.compute_dtype(src))
+        output, src_cls = hip_ops.TapClsFn.apply(src)
+        for mod in self.layers:
+            output = mod(output)
+        if self.norm is not None:
+            output = self.norm(output)
+        return output, src_cls
+
 
 class SpectralPatchEmbed(nn.Module):
     """Per-patch Re(rfft2 ortho) * learnable frequency weights -> Linear -> CLS + position (+dropout)
@@ -171,8 +182,16 @@ class SpectreViT(nn.Module):
         if torch.is_grad_enabled() and x.is_cuda and torch.is_autocast_enabled("cuda"):
             hip_ops.refresh_weight_shadows(self, self._shadow_weights)  # all layers' bf16 weight copies in one launch
         x = self.embeddings_block(x)
-        cls_token = self.encoder_blocks.forward_cls(x)
-        x = self.mlp_head(cls_token)
+        head = self.mlp_head[0] if len(self.mlp_head) == 1 and isinstance(self.mlp_head[0], SpectreLinear) else None
+        if (head is not None and (head.drop_p == 0.0 or not self.training) and x.is_cuda
+                and hip_ops.small_head_ok(x.shape[0], head.out_channels, head.in_channels)):
+            # the class head over the B CLS rows: CLS add + Linear + LayerNorm + GELU + pooled skip in one launch (fp32 logits)
+            output, src_cls = self.encoder_blocks.forward_cls_parts(x)
+            lin, ln = head.local_head[0], head.local_head[1]
+            x, cls_token = hip_ops.ClsHeadFn.apply(output, src_cls, lin.weight, lin.bias, ln.weight, ln.bias)
+        else:
+            cls_token = self.encoder_blocks.forward_cls(x)
+            x = self.mlp_head(cls_token)
         if return_features:
             return x, cls_token
         return x
