@@ -251,8 +251,11 @@ int spv_fwht(const void* x, void* y, const void* residual, int rows, int n_in, i
  * W_full = (proj.weight * freq_h (x) freq_w) . R, R = Re(rfft2 ortho) it is SpectralPatchEmbed
  * (spectre_vit/models/spectre/spectre.py:124-156).  The contraction itself is spv_gemm_nt_grouped_rows;
  * these entry points are the plumbing around it:
- *   spv_patchify        pixel blocks -> [B*Np, ld>=K] rows (or the [K, ld>=B*Np] transpose for the weight gradient)
- *   spv_embed_posbias   bias2d[t][e] = pos[1+t][e] + bias[e]
+ *   spv_patchify        pixel blocks -> [B*Np, ld>=K] rows (transposed = 0), the [K, ld>=B*Np] transpose (1), or token rows
+ *                       [B][Np+1][ld>=K] whose first row per image -- the CLS slot -- is zero (2: the token GEMM and the TN
+ *                       weight-gradient GEMM read that layout as it lies)
+ *   spv_embed_posbias   bias2d[t][e] = pos[1+t][e] + bias[e]; with cls != NULL one more row in front: cls[e] + pos[0][e]
+ *                       (out then has patches + 1 rows and the GEMM over the zero CLS rows writes the CLS tokens)
  *   spv_embed_cls_rows  tokens[b,0,:] = cls + pos[0]
  *   spv_spectral_fold / _bwd   W_full from (proj.weight, freq_h, freq_w) and the gradients back
  *                       (scratch: embed*chans*patch*(patch/2+1) floats)
@@ -265,7 +268,7 @@ int spv_patchify(const float* img, void* out, int batch, int chans, int height, 
  * (pixel / 255 - mean[c]) * inv_std[c]. */
 int spv_patchify_u8(const unsigned char* img_hwc, const float* mean, const float* inv_std, void* out, int batch, int chans,
                     int height, int width, int patch, int ld, int transposed, int out_dtype, void* stream);
-int spv_embed_posbias(const float* pos, const float* bias, float* out, int patches, int embed, void* stream);
+int spv_embed_posbias(const float* pos, const float* bias, const float* cls, float* out, int patches, int embed, void* stream);
 int spv_embed_cls_rows(const float* cls, const float* pos, void* tokens, int batch, int tokens_per_image, int embed,
                        int dtype, void* stream);
 int spv_spectral_fold(const float* proj_w, const float* freq_h, const float* freq_w, float* w_full, int embed,

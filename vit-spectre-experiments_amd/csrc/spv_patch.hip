@@ -20,12 +20,19 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
                                                        int W, int P, int ld, int transposed, int bf) {
     const int nH = H / P, nW = W / P, Np = nH * nW, K = C * P * P;
     const int64_t rows = (int64_t)B * Np;
-    const int64_t total = transposed ? (int64_t)K * ld : rows * ld;
+    // transposed == 2: token rows [B][Np + 1][ld], row 0 of every image (the CLS slot) zero -- the layout the token GEMM and the TN
+    // weight-gradient GEMM both read as it lies
+    const int64_t total = transposed == 1 ? (int64_t)K * ld : (transposed == 2 ? (int64_t)B * (Np + 1) * ld : rows * ld);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t row;
         int k;
-        if (transposed) { k = (int)(e / ld); row = e % ld; }
+        if (transposed == 1) { k = (int)(e / ld); row = e % ld; }
         else { row = e / ld; k = (int)(e % ld); }
+        if (transposed == 2) {
+            const int64_t b2 = row / (Np + 1);
+            const int t2 = (int)(row % (Np + 1));
+            row = t2 == 0 ? rows : b2 * Np + t2 - 1;   // rows = "no such row": zero
+        }
         float v = 0.0f;
         if (row < rows && k < K) {
             const int b = (int)(row / Np), n = (int)(row % Np);
@@ -45,12 +52,19 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* _
                                                           int H, int W, int P, int ld, int transposed, int bf) {
     const int nH = H / P, nW = W / P, Np = nH * nW, K = C * P * P;
     const int64_t rows = (int64_t)B * Np;
-    const int64_t total = transposed ? (int64_t)K * ld : rows * ld;
+    // transposed == 2: token rows [B][Np + 1][ld], row 0 of every image (the CLS slot) zero -- the layout the token GEMM and the TN
+    // weight-gradient GEMM both read as it lies
+    const int64_t total = transposed == 1 ? (int64_t)K * ld : (transposed == 2 ? (int64_t)B * (Np + 1) * ld : rows * ld);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t row;
         int k;
-        if (transposed) { k = (int)(e / ld); row = e % ld; }
+        if (transposed == 1) { k = (int)(e / ld); row = e % ld; }
         else { row = e / ld; k = (int)(e % ld); }
+        if (transposed == 2) {
+            const int64_t b2 = row / (Np + 1);
+            const int t2 = (int)(row % (Np + 1));
+            row = t2 == 0 ? rows : b2 * Np + t2 - 1;   // rows = "no such row": zero
+        }
         float v = 0.0f;
         if (row < rows && k < K) {
             const int b = (int)(row / Np), n = (int)(row % Np);
@@ -64,11 +78,13 @@ __global__ __launch_bounds__(256) void patchify_u8_kernel(const unsigned char* _
 }
 
 // posbias[t][e] = pos[1 + t][e] + bias[e]
+// with cls: one more row in front, out[0][e] = cls[e] + pos[0][e] -- the token GEMM over the zero CLS patch row then writes the CLS token
 __global__ __launch_bounds__(256) void posbias_kernel(const float* __restrict__ pos, const float* __restrict__ bias,
-                                                      float* __restrict__ out, int Np, int E) {
-    const int total = Np * E;
+                                                      const float* __restrict__ cls, float* __restrict__ out, int Np, int E) {
+    const int lead = cls != nullptr ? E : 0;
+    const int total = Np * E + lead;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
-        out[i] = pos[E + i] + bias[i % E];
+        out[i] = i < lead ? cls[i] + pos[i] : pos[E + i - lead] + bias[(i - lead) % E];
 }
 
 // tokens[b][0][e] = cls[e] + pos[0][e]
@@ -187,8 +203,8 @@ extern "C" int spv_patchify(const float* img, void* out, int batch, int chans, i
     SPV_CHECK(out_dtype == SPV_F32 || out_dtype == SPV_BF16, "spv_patchify: bad dtype");
     const int Np = (height / patch) * (width / patch), K = chans * patch * patch;
     const int64_t rows = (int64_t)batch * Np;
-    SPV_CHECK(transposed ? ld >= rows : ld >= K, "spv_patchify: ld=%d too small", ld);
-    const int64_t total = transposed ? (int64_t)K * ld : rows * ld;
+    SPV_CHECK(transposed >= 0 && transposed <= 2 && (transposed == 1 ? ld >= rows : ld >= K), "spv_patchify: ld=%d too small", ld);
+    const int64_t total = transposed == 1 ? (int64_t)K * ld : (transposed == 2 ? (int64_t)batch * (Np + 1) * ld : rows * ld);
     hipLaunchKernelGGL(patchify_kernel, dim3(ew_blocks(total)), dim3(256), 0, static_cast<hipStream_t>(stream), img, out, batch,
                        chans, height, width, patch, ld, transposed, out_dtype == SPV_BF16);
     SPV_LAUNCH_CHECK("spv_patchify");
@@ -202,18 +218,18 @@ extern "C" int spv_patchify_u8(const unsigned char* img_hwc, const float* mean, 
     SPV_CHECK(mean != nullptr && inv_std != nullptr, "spv_patchify_u8: mean / inv_std missing");
     const int Np = (height / patch) * (width / patch), K = chans * patch * patch;
     const int64_t rows = (int64_t)batch * Np;
-    SPV_CHECK(transposed ? ld >= rows : ld >= K, "spv_patchify_u8: ld=%d too small", ld);
-    const int64_t total = transposed ? (int64_t)K * ld : rows * ld;
+    SPV_CHECK(transposed >= 0 && transposed <= 2 && (transposed == 1 ? ld >= rows : ld >= K), "spv_patchify_u8: ld=%d too small", ld);
+    const int64_t total = transposed == 1 ? (int64_t)K * ld : (transposed == 2 ? (int64_t)batch * (Np + 1) * ld : rows * ld);
     hipLaunchKernelGGL(patchify_u8_kernel, dim3(ew_blocks(total)), dim3(256), 0, static_cast<hipStream_t>(stream), img_hwc, mean,
                        inv_std, out, batch, chans, height, width, patch, ld, transposed, out_dtype == SPV_BF16);
     SPV_LAUNCH_CHECK("spv_patchify_u8");
     return 0;
 }
 
-extern "C" int spv_embed_posbias(const float* pos, const float* bias, float* out, int patches, int embed, void* stream) {
+extern "C" int spv_embed_posbias(const float* pos, const float* bias, const float* cls, float* out, int patches, int embed, void* stream) {
     SPV_CHECK(patches > 0 && embed > 0, "spv_embed_posbias: empty");
-    hipLaunchKernelGGL(posbias_kernel, dim3(ew_blocks((int64_t)patches * embed)), dim3(256), 0, static_cast<hipStream_t>(stream), pos,
-                       bias, out, patches, embed);
+    hipLaunchKernelGGL(posbias_kernel, dim3(ew_blocks((int64_t)(patches + 1) * embed)), dim3(256), 0, static_cast<hipStream_t>(stream), pos,
+                       bias, cls, out, patches, embed);
     SPV_LAUNCH_CHECK("spv_embed_posbias");
     return 0;
 }

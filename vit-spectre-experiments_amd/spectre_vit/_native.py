@@ -69,7 +69,7 @@ SIGNATURES = {
     "spv_haar_dwt": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "spv_patchify": [c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_patchify_u8": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
-    "spv_embed_posbias": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "spv_embed_posbias": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "spv_embed_cls_rows": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_spectral_fold": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "spv_spectral_fold_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],

@@ -390,6 +390,8 @@ def _weight_grad(dh, x, rows, n, k, sink=None):
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
     # ~2 workgroups per CU: measured optimum on the 768 x 512 x 33280 weight gradient (21 splits: 51 us; 12: 69; 42: 56; 64: 64)
     splits = max(1, min(512 // tiles, (rows + 511) // 512 if tiles >= 8 else (rows + 63) // 64))
+    if tiles < 8:
+        splits = min(splits, 64)  # the patch-embedding gradient (512 x 48): 128 slices made the reduce (10 us) as long as the GEMM
     if _TN_DMA and n % 128 == 0 and k % 128 == 0 and rows % 64 == 0 and dh.dtype == torch.bfloat16:
         # the LDS-DMA kernel (spv_gemm.hip gemm_tn_dma_kernel; opt-in, SPV_TN_DMA=1) runs ONE 8-wave workgroup per CU: one dispatch
         # round of <= 256 workgroups (24 tiles x 10 K-slices of 52 K-tiles at the layer shapes)
@@ -761,18 +763,19 @@ class PatchEmbedFn(torch.autograd.Function):
         if K % mult or E % mult:
             raise ValueError(f"patch embedding: C*P*P={K} and embed_dim={E} must be multiples of {mult}")
         st = _stream()
-        patches = torch.empty((B * Np, K), dtype=dtype, device=dev)
+        # token rows [B][T][K], the CLS slot of every image zero: the GEMM below then writes cls + pos[0] there by itself (its row bias
+        # holds that sum in row 0), and the backward's TN weight-gradient GEMM reads the same matrix against dtok as both lie in memory
+        patches = torch.empty((B * T, K), dtype=dtype, device=dev)
         if u8:
-            _native.call("spv_patchify_u8", _p(img), _p(norm[0]), _p(norm[1]), _p(patches), B, C, H, W, patch, K, 0, _DT[dtype], st)
+            _native.call("spv_patchify_u8", _p(img), _p(norm[0]), _p(norm[1]), _p(patches), B, C, H, W, patch, K, 2, _DT[dtype], st)
         else:
-            _native.call("spv_patchify", _p(img), _p(patches), B, C, H, W, patch, K, 0, _DT[dtype], st)
+            _native.call("spv_patchify", _p(img), _p(patches), B, C, H, W, patch, K, 2, _DT[dtype], st)
         wc = w_full if dtype == torch.float32 else _raw_cast(w_full, dtype)
-        posbias = torch.empty((Np, E), dtype=torch.float32, device=dev)
-        _native.call("spv_embed_posbias", _p(pos), _p(bias), _p(posbias), Np, E, st)
+        posbias = torch.empty((T, E), dtype=torch.float32, device=dev)
+        _native.call("spv_embed_posbias", _p(pos), _p(bias), _p(cls), _p(posbias), Np, E, st)
         tokens = torch.empty((B, T, E), dtype=dtype, device=dev)
-        _native.call("spv_gemm_nt_grouped_rows", _p(patches), _p(wc), 0, _p(posbias), _p(tokens), B * Np, E, K, K, K, E,
-                     _DT[dtype], _DT[dtype], Np, T, 1, st)
-        _native.call("spv_embed_cls_rows", _p(cls), _p(pos), _p(tokens), B, T, E, _DT[dtype], st)
+        _native.call("spv_gemm_nt_grouped_rows", _p(patches), _p(wc), 0, _p(posbias), _p(tokens), B * T, E, K, K, K, E,
+                     _DT[dtype], _DT[dtype], T, T, 0, st)
         # bf16: the backward's TN weight-gradient GEMM reads the patch matrix as it lies here (3 MB), so keep it
         ctx.save_for_backward(None if u8 else img, patches if (dtype == torch.bfloat16 or u8) else None)
         ctx.meta = (B, C, H, W, patch, E, K, Np, T, dtype, cls.shape, pos.shape)
@@ -798,9 +801,7 @@ class PatchEmbedFn(torch.autograd.Function):
         if patches is not None and dtok.dtype == torch.bfloat16:
             # dW = dtok^T . P over all B*T token rows, with P the patch matrix widened by a zero row per image (the CLS
             # row): the TN kernel then takes dtok as it lies in memory -- no transposed copies of a 34 MB tensor
-            pfull = torch.zeros((B, T, K), dtype=dtok.dtype, device=dev)
-            pfull[:, 1:, :] = patches.view(B, Np, K)
-            dwf = _weight_grad(dtok.view(B * T, E), pfull.view(B * T, K), B * T, E, K)
+            dwf = _weight_grad(dtok.view(B * T, E), patches, B * T, E, K)
             join_side_stream()
             return None, dwf, dbias, dcls, dpos_full, None, None, None
         rows = B * Np
@@ -809,7 +810,7 @@ class PatchEmbedFn(torch.autograd.Function):
         _native.call("spv_cast_transpose", _p(dtok), _dt(dtok), _p(dyt), _dt(dyt), rows, E, ld, Np, T, 1, st)
         pt = torch.empty((K, ld), dtype=dtok.dtype, device=dev)
         if img is None:  # uint8 input: the forward kept the normalised patch matrix instead of a float image
-            _native.call("spv_cast_transpose", _p(patches), _dt(patches), _p(pt), _dt(pt), rows, K, ld, 0, 0, 0, st)
+            _native.call("spv_cast_transpose", _p(patches), _dt(patches), _p(pt), _dt(pt), rows, K, ld, Np, T, 1, st)  # token rows -> patch rows
         else:
             _native.call("spv_patchify", _p(img), _p(pt), B, C, H, W, patch, ld, 1, _dt(pt), st)
         dwf = torch.empty((E, K), dtype=torch.float32, device=dev)
@@ -907,7 +908,7 @@ class TapClsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         _require_gpu(x)
-        return x.view_as(x), x[:, 0, :].contiguous()
+        return x.view_as(x), x[:, 0, :]   # a strided view: the class head reads the CLS rows where they lie
 
     @staticmethod
     def backward(ctx, gx, gcls):
@@ -919,6 +920,24 @@ class TapClsFn(torch.autograd.Function):
             gx = gx.contiguous()
         gx[:, 0, :] += gcls.to(gx.dtype)  # in place: this edge owns the tensor (it was written for it by the first layer's backward)
         return gx
+
+
+_cls_grad_bufs = {}
+
+
+def _cls_row_gradient(shape, dtype, dev, rows):
+    """The stack's output gradient when only the CLS rows carry one: a (B, N, E) tensor that is zero off row 0.  The buffer is kept
+    across steps -- nothing ever writes its other rows (the consumers read it; TapClsFn adds in place to row 0 only) -- so a step
+    costs the CLS-row copy, not a 34 MB fill."""
+    key = (tuple(shape), dtype, dev.index)   # not per stream: a graph capture runs on its own stream and must find the warm-up's buffer
+    full = _cls_grad_bufs.get(key)
+    if full is None:
+        if len(_cls_grad_bufs) > 8:
+            _cls_grad_bufs.clear()
+        full = torch.zeros(shape, dtype=dtype, device=dev)
+        _cls_grad_bufs[key] = full
+    full[:, 0, :] = rows
+    return full
 
 
 class ClsAddFn(torch.autograd.Function):
@@ -934,9 +953,7 @@ class ClsAddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         shape, dtype = ctx.meta
-        full = torch.zeros(shape, dtype=dtype, device=g.device)
-        full[:, 0, :] = g
-        return full, g
+        return _cls_row_gradient(shape, dtype, g.device, g), g
 
 
 # ------------------------------------------------------------------------------------------------
@@ -959,7 +976,8 @@ class ClsHeadFn(torch.autograd.Function):
         n = weight.shape[0]
         if not out.is_contiguous():
             out = out.contiguous()
-        src_cls = src_cls.contiguous()
+        if src_cls.stride(-1) != 1:
+            src_cls = src_cls.contiguous()
         if src_cls.dtype != out.dtype or weight.dtype != torch.float32 or not weight.is_contiguous():
             raise ValueError("ClsHeadFn: src_cls must have the stack's dtype and the head weight must be contiguous fp32")
         dev = out.device
@@ -968,7 +986,7 @@ class ClsHeadFn(torch.autograd.Function):
         xs = torch.empty((B, E), dtype=torch.float32, device=dev)
         mean = torch.empty((B,), dtype=torch.float32, device=dev)
         rstd = torch.empty((B,), dtype=torch.float32, device=dev)
-        _native.call("spv_small_sl_fwd", _p(out), N * E, _p(src_cls), E, _p(weight), _p(bias), _p(gamma), _p(beta), _p(logits), _p(h),
+        _native.call("spv_small_sl_fwd", _p(out), N * E, _p(src_cls), src_cls.stride(0), _p(weight), _p(bias), _p(gamma), _p(beta), _p(logits), _p(h),
                      _p(xs), _p(mean), _p(rstd), B, n, E, _dt(out), _stream())
         ctx.save_for_backward(h, xs, mean, rstd, weight, gamma, beta)
         ctx.meta = (out.shape, out.dtype)
@@ -998,16 +1016,14 @@ class ClsHeadFn(torch.autograd.Function):
                      _p(dw), _p(dgamma), _p(dbeta), _p(dbias), _p(partials), B, n, E, _DT[dtype], _stream())
         if dfeats is not None:
             dx = dx + dfeats.to(dx.dtype)
-        full = torch.zeros(shape, dtype=dtype, device=dev)  # the stack's gradient is dense: zero off the CLS row
-        full[:, 0, :] = dx
-        return full, dx, dw, dbias, dgamma, dbeta
+        return _cls_row_gradient(shape, dtype, dev, dx), dx, dw, dbias, dgamma, dbeta  # the stack's gradient is dense: zero off the CLS row
 
 
 _ce_workspaces = {}
 
 
 def _ce_workspace(dev):
-    key = (dev.index, _stream())
+    key = dev.index   # one loss per step and device; not per stream, so that a graph capture reuses the warm-up's (zeroed) counter
     ws = _ce_workspaces.get(key)
     if ws is None:
         ws = torch.zeros((_native.call("spv_cross_entropy_workspace_floats"),), dtype=torch.float32, device=dev)
