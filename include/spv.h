@@ -99,6 +99,18 @@ int spv_set_reserved_cus(int n);
  * ds_read_b64_tr_b16); M, N, lda, ldb multiples of 8; split-K as above. */
 int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
                 int accumulate, int splits, void* workspace, void* stream);
+/* The same, with the fold of a SpectreLinear tail backward's per-workgroup partial column sums riding in the split-K reduce launch
+ * as extra workgroups: out[p][c] = sum_w partials[w][p][c], p < nsum <= 5 (dgamma, dbeta, dbias[, dgamma2, dbeta2]), c < n, fixed
+ * order.  The tail backward is then called with its parameter-gradient pointers NULL (it writes the partials and launches no fold);
+ * parts = spv_tail_bwd_parts(rows).  With splits == 1 the fold runs as its own launch. */
+typedef struct spv_fold_job {
+    const float* partials;
+    float* out[5];
+    int parts, nsum, n;
+} spv_fold_job;
+int spv_tail_bwd_parts(int rows);
+int spv_gemm_tn_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
+                     int accumulate, int splits, void* workspace, const spv_fold_job* fold, void* stream);
 
 /* ---- SpectreLinear tail: out = dropout(GELU_erf(LayerNorm(h)) + adaptive_avg_pool(x)) ---------
  * spectre_vit/models/spectre/layers.py:85-101 (LN eps 1e-5, nn.GELU exact, AdaptiveAvgPool1d over the

@@ -747,3 +747,29 @@ def test_cross_entropy_module_contract():
     z = torch.randn(8, 5, device=dev())
     bad = torch.full((8,), 7, device=dev())
     assert torch.isnan(crit(z, bad))  # a label outside [0, classes) poisons the loss; it never reads out of bounds
+
+
+@pytest.mark.parametrize("rows,n,k", [(33280, 768, 512), (1300, 512, 768), (700, 64, 64)])
+def test_fold_rides_in_the_split_k_reduce(ops, monkeypatch, rows, n, k):
+    """spv_gemm_tn_fold: the tail backward's dgamma / dbeta / dbias fold as extra workgroups of the weight gradient's split-K reduce
+    must give, bit for bit, what the tail backward's own fold launch and a plain spv_gemm_tn give (same sums, same order)."""
+    torch.manual_seed(rows + n)
+    bf = torch.bfloat16
+    x = torch.randn(rows, k, device=dev()).to(bf)
+    W = (torch.randn(n, k, device=dev()) / k ** 0.5)
+    b, g, be = torch.randn(n, device=dev()) * 0.1, torch.rand(n, device=dev()) + 0.5, torch.randn(n, device=dev()) * 0.1
+    dy = torch.randn(rows, n, device=dev()).to(bf)
+
+    def run():
+        ps = [t_.clone().requires_grad_(True) for t_ in (W, b, g, be)]
+        xin = x.clone().requires_grad_(True)
+        ops.spectre_linear(xin, *ps, 0.0, False).backward(dy)
+        return [xin.grad] + [p_.grad for p_ in ps]
+
+    assert ops._fold_rides(bf, rows, n, k)
+    rode = run()
+    monkeypatch.setenv("SPV_NO_FOLD_RIDE", "1")
+    assert not ops._fold_rides(bf, rows, n, k)
+    plain = run()
+    for a, c, name in zip(rode, plain, ("dx", "dW", "dbias", "dgamma", "dbeta")):
+        assert torch.equal(a, c), name

@@ -99,6 +99,53 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(row_lane(v, 0), row_lane(v, 16)), fmaxf(row_lane(v, 32), row_lane(v, 48)));
 }
 
+// ---------------------------------------------------------------- fold of per-workgroup partial column sums
+// out[p][c] = sum_w partials[w][p][c] (p < np <= 5, c < n), in a fixed order.  One 1024-thread workgroup covers FOLD_COLS columns;
+// block `bid` of cdiv(np * n, FOLD_COLS).  Used by the row kernels' own fold launch and -- so that the backward of a layer does not
+// pay a launch for it -- as extra workgroups of the weight gradient's split-K reduce (spv_gemm_tn_fold).
+constexpr int FOLD_COLS = 16, FOLD_ROWS = 64;
+struct FoldJob {
+    const float* partials;
+    float* o[5];
+    int parts, np, n;
+};
+__device__ __forceinline__ void fold_partials_block(const FoldJob& j, int bid, int tid) {
+    __shared__ float red[FOLD_ROWS][FOLD_COLS + 1];
+    const int cx = tid % FOLD_COLS, py = tid / FOLD_COLS;
+    const int c = bid * FOLD_COLS + cx;
+    const int total = j.np * j.n;
+    const float* partials = j.partials;
+    float s = 0.0f;
+    if (c < total) {
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        int w = py;
+        for (; w + 3 * FOLD_ROWS < j.parts; w += 4 * FOLD_ROWS) {
+            s0 += partials[(size_t)w * total + c];
+            s1 += partials[(size_t)(w + FOLD_ROWS) * total + c];
+            s2 += partials[(size_t)(w + 2 * FOLD_ROWS) * total + c];
+            s3 += partials[(size_t)(w + 3 * FOLD_ROWS) * total + c];
+        }
+        for (; w < j.parts; w += FOLD_ROWS) s0 += partials[(size_t)w * total + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[py][cx] = s;
+    __syncthreads();
+    // 64 -> 4 -> 1 in a fixed order
+    if (py < 4) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < FOLD_ROWS / 4; ++q) t += red[py * (FOLD_ROWS / 4) + q][cx];
+        red[py * (FOLD_ROWS / 4)][cx] = t;
+    }
+    __syncthreads();
+    if (py == 0 && c < total) {
+        const float t = (red[0][cx] + red[FOLD_ROWS / 4][cx]) + (red[FOLD_ROWS / 2][cx] + red[3 * FOLD_ROWS / 4][cx]);
+        const int p = c / j.n, cc = c % j.n;
+        float* o = j.o[p];
+        if (o) o[cc] = t;
+    }
+}
+
 // ---------------------------------------------------------------- math
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -1212,15 +1212,14 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const bf16_t* __restri
 }
 
 template <typename TO>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
-                                                            TO* __restrict__ C, int M, int N, int ldc, int splits,
-                                                            int accumulate) {
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ ws, const float* __restrict__ bias, TO* __restrict__ C, int M, int N,
+                                                   int ldc, int splits, int accumulate, size_t bid, size_t nblocks, int tid, int nthreads) {
     const size_t total = (size_t)M * N;
     if ((N & 3) == 0) {
         // four consecutive columns per thread, the slabs read four at a time with independent 16-byte loads (the scalar
         // loop was a chain of dependent 4-byte loads: 9.3 us for the weight gradient's 12 x 1.5 MB, twice its bytes' worth)
         const size_t quads = total >> 2;
-        for (size_t qd = (size_t)blockIdx.x * blockDim.x + threadIdx.x; qd < quads; qd += (size_t)gridDim.x * blockDim.x) {
+        for (size_t qd = bid * nthreads + tid; qd < quads; qd += nblocks * nthreads) {
             const size_t e = qd << 2;
             const int row = (int)(e / N), col = (int)(e % N);
             float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1251,7 +1250,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
         return;
     }
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    for (size_t e = bid * nthreads + tid; e < total; e += nblocks * nthreads) {
         const int row = (int)(e / N), col = (int)(e % N);
         float v = 0.0f;
         for (int s = 0; s < splits; ++s) v += ws[(size_t)s * total + e];
@@ -1261,6 +1260,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         store_out<TO>(cp, v);
     }
 }
+
+template <typename TO>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                            TO* __restrict__ C, int M, int N, int ldc, int splits,
+                                                            int accumulate) {
+    splitk_reduce_body<TO>(ws, bias, C, M, N, ldc, splits, accumulate, blockIdx.x, gridDim.x, threadIdx.x, 256);
+}
+
+// the split-K reduce of a weight gradient with the fold of the same layer's dgamma / dbeta / dbias partials as extra workgroups: the
+// fold launch of a tail backward (5.5 us at its floor, eight per step) rides along in a launch that happens anyway
+template <typename TO>
+__global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void splitk_reduce_fold_kernel(const float* __restrict__ ws, TO* __restrict__ C, int M, int N,
+                                                                                   int ldc, int splits, int accumulate, int reduce_blocks,
+                                                                                   FoldJob job) {
+    if ((int)blockIdx.x < reduce_blocks)
+        splitk_reduce_body<TO>(ws, nullptr, C, M, N, ldc, splits, accumulate, blockIdx.x, reduce_blocks, threadIdx.x, FOLD_COLS * FOLD_ROWS);
+    else
+        fold_partials_block(job, (int)blockIdx.x - reduce_blocks, threadIdx.x);
+}
+__global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void fold_only_kernel(FoldJob job) { fold_partials_block(job, blockIdx.x, threadIdx.x); }
 
 inline int kend_len(int K, int k_per_split) { return K < k_per_split ? K : k_per_split; }
 
@@ -1408,8 +1427,8 @@ static int gemm_entry(const void* A, const void* B, const float* bias, void* C, 
     return launch_gemm<float, float>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
 }
 
-extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
-                           int accumulate, int splits, void* workspace, void* stream) {
+static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
+                        int accumulate, int splits, void* workspace, void* stream, const spv_fold_job* fold) {
     SPV_COUNT_PATH(SPV_PATH_GEMM_TN);
     SPV_CHECK(M > 0 && N > 0 && K > 0, "spv_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
     SPV_CHECK(out_dtype == SPV_F32 || out_dtype == SPV_BF16, "spv_gemm_tn: bad out_dtype %d", out_dtype);
@@ -1474,7 +1493,30 @@ extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, 
 #undef SPV_TN
     SPV_LAUNCH_CHECK("spv_gemm_tn");
     }
+    FoldJob job{};
+    int fold_blocks = 0;
+    if (fold != nullptr) {
+        SPV_CHECK(fold->partials != nullptr && fold->parts > 0 && fold->nsum >= 1 && fold->nsum <= 5 && fold->n > 0, "spv_gemm_tn_fold: bad fold job");
+        job.partials = fold->partials;
+        for (int i = 0; i < 5; ++i) job.o[i] = i < fold->nsum ? fold->out[i] : nullptr;
+        job.parts = fold->parts;
+        job.np = fold->nsum;
+        job.n = fold->n;
+        fold_blocks = cdiv((int64_t)fold->nsum * fold->n, FOLD_COLS);
+    }
     if (splits > 1) {
+        if (fold_blocks > 0) {
+            constexpr int RT1 = FOLD_COLS * FOLD_ROWS;
+            const int blocks = (int)std::min<int64_t>(((int64_t)M * N / ((N & 3) == 0 ? 4 : 1) + RT1 - 1) / RT1, 1024);
+            if (out_dtype == SPV_BF16)
+                hipLaunchKernelGGL((splitk_reduce_fold_kernel<bf16_t>), dim3(blocks + fold_blocks), dim3(RT1), 0, st, ws, (bf16_t*)C, M, N, ldc, splits,
+                                   accumulate, blocks, job);
+            else
+                hipLaunchKernelGGL((splitk_reduce_fold_kernel<float>), dim3(blocks + fold_blocks), dim3(RT1), 0, st, ws, (float*)C, M, N, ldc, splits,
+                                   accumulate, blocks, job);
+            SPV_LAUNCH_CHECK("spv_gemm_tn_fold(split-k reduce + fold)");
+            return 0;
+        }
         int blocks = (int)std::min<int64_t>(((int64_t)M * N / ((N & 3) == 0 ? 4 : 1) + 255) / 256, 2048);
         if (out_dtype == SPV_BF16)
             hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, st, ws, (const float*)nullptr, (bf16_t*)C, M, N,
@@ -1484,6 +1526,20 @@ extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, 
                                splits, accumulate);
         SPV_LAUNCH_CHECK("spv_gemm_tn(split-k reduce)");
     }
+    if (fold_blocks > 0 && splits <= 1) {   // no reduce to ride on: the fold runs by itself
+        hipLaunchKernelGGL(fold_only_kernel, dim3(fold_blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, job);
+        SPV_LAUNCH_CHECK("spv_gemm_tn_fold(fold)");
+    }
     return 0;
+}
+
+extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
+                           int accumulate, int splits, void* workspace, void* stream) {
+    return gemm_tn_impl(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, accumulate, splits, workspace, stream, nullptr);
+}
+
+extern "C" int spv_gemm_tn_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
+                                int accumulate, int splits, void* workspace, const spv_fold_job* fold, void* stream) {
+    return gemm_tn_impl(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, accumulate, splits, workspace, stream, fold);
 }
 

@@ -526,44 +526,12 @@ __global__ __launch_bounds__(RT) void addln_bwd_kernel(const void* __restrict__ 
 // out[p][c] = sum_w partials[w][p][c]; a workgroup of 1024 threads owns 16 columns (64-byte segments), 64 thread rows
 // split the slabs (<= 16 loads each at 1024 slabs: the kernel is latency bound, so the loads must be spread thin),
 // fixed summation order
-constexpr int FOLD_COLS = 16, FOLD_ROWS = 64;
 __global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void fold_partials_kernel(const float* __restrict__ partials, float* __restrict__ o0,
                                                                              float* __restrict__ o1, float* __restrict__ o2,
                                                                              int parts, int np, int n, float* __restrict__ o3 = nullptr,
                                                                              float* __restrict__ o4 = nullptr) {
-    __shared__ float red[FOLD_ROWS][FOLD_COLS + 1];
-    const int cx = threadIdx.x % FOLD_COLS, py = threadIdx.x / FOLD_COLS;
-    const int c = blockIdx.x * FOLD_COLS + cx;
-    const int total = np * n;
-    float s = 0.0f;
-    if (c < total) {
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-        int w = py;
-        for (; w + 3 * FOLD_ROWS < parts; w += 4 * FOLD_ROWS) {
-            s0 += partials[(size_t)w * total + c];
-            s1 += partials[(size_t)(w + FOLD_ROWS) * total + c];
-            s2 += partials[(size_t)(w + 2 * FOLD_ROWS) * total + c];
-            s3 += partials[(size_t)(w + 3 * FOLD_ROWS) * total + c];
-        }
-        for (; w < parts; w += FOLD_ROWS) s0 += partials[(size_t)w * total + c];
-        s = (s0 + s1) + (s2 + s3);
-    }
-    red[py][cx] = s;
-    __syncthreads();
-    // 64 -> 4 -> 1 in a fixed order
-    if (py < 4) {
-        float t = 0.0f;
-#pragma unroll
-        for (int q = 0; q < FOLD_ROWS / 4; ++q) t += red[py * (FOLD_ROWS / 4) + q][cx];
-        red[py * (FOLD_ROWS / 4)][cx] = t;
-    }
-    __syncthreads();
-    if (py == 0 && c < total) {
-        const float t = (red[0][cx] + red[FOLD_ROWS / 4][cx]) + (red[FOLD_ROWS / 2][cx] + red[3 * FOLD_ROWS / 4][cx]);
-        const int p = c / n, cc = c % n;
-        float* o = p == 0 ? o0 : (p == 1 ? o1 : (p == 2 ? o2 : (p == 3 ? o3 : o4)));
-        if (o) o[cc] = t;
-    }
+    const FoldJob j{partials, {o0, o1, o2, o3, o4}, parts, np, n};
+    fold_partials_block(j, blockIdx.x, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -972,6 +940,8 @@ inline int pool_mode_of(int n, int k_in) {
 }  // namespace
 
 extern "C" int64_t spv_rowop_partial_floats(int n) { return (int64_t)BWD_MAX_WG * 3 * n; }
+// partial slabs a tail backward over `rows` rows writes (its grid): what a caller that folds them itself (spv_gemm_tn_fold) passes on
+extern "C" int spv_tail_bwd_parts(int rows) { return std::min(cdiv(rows, RW), BWD_MAX_WG); }
 
 extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* gamma, const float* beta, void* out,
                                     float* mean, float* rstd, int rows, int n, int k_in, int dtype, int out_dtype,
@@ -1033,7 +1003,7 @@ static int tail_bwd_impl(const void* dout, const void* h, const float* mean, con
             if (fast) hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, true, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{}, up); \
             else hipLaunchKernelGGL((tail_bwd_lc_kernel<CO, CI, false, false>), dim3(lwgs), dim3(RT), (size_t)RW * 3 * n * sizeof(float), lst, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, dbf, p_drop, seed, dx_add, TailLn2{}, up);    \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc)");                                                                     \
-            hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, lst, partials, dgamma, dbeta, dbias, lwgs, 3, n); \
+            if (dgamma != nullptr) hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, lst, partials, dgamma, dbeta, dbias, lwgs, 3, n); \
             SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(lc fold)");                                                                \
             return 0;                                                                                                         \
         }
@@ -1049,7 +1019,7 @@ static int tail_bwd_impl(const void* dout, const void* h, const float* mean, con
     TAIL_DISPATCH(cfg, dtype == SPV_BF16, tail_bwd_kernel, dim3(wgs), lds, st, dout, h, mean, rstd, gamma, beta, dh,
                  dx_pool, partials, rows, n, k_in, dtype == SPV_BF16, dout_dtype == SPV_BF16, p_drop, seed, pm, dx_add);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd");
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, wgs, 3, n);
+    if (dgamma != nullptr) hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, wgs, 3, n);
     SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(fold)");
     return 0;
 }
@@ -1108,9 +1078,10 @@ extern "C" int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const 
                                        float* dbeta, float* dbias, float* partials, int rows, int n, int k_in, int dtype, float p_drop,
                                        uint64_t seed, void* stream) {
     SPV_CHECK(rows > 0 && spv_tail_ln_supported(n, k_in, dtype), "spv_spectre_tail_ln_bwd: unsupported shape %d -> %d / dtype %d", k_in, n, dtype);
-    SPV_CHECK(dout2 && f3 && res && mean2 && rstd2 && gamma2 && ds && dgamma2 && dbeta2 && h && mean && rstd && gamma && beta && dh &&
-                  dgamma && dbeta && dbias && partials,
+    SPV_CHECK(dout2 && f3 && res && mean2 && rstd2 && gamma2 && ds && h && mean && rstd && gamma && beta && dh && partials,
               "spv_spectre_tail_ln_bwd: null pointer");
+    SPV_CHECK((dgamma && dbeta && dbias && dgamma2 && dbeta2) || (!dgamma && !dbeta && !dbias && !dgamma2 && !dbeta2),
+              "spv_spectre_tail_ln_bwd: the five parameter gradients are given together, or all NULL (the caller folds the partials)");
     const int bfl = dtype == SPV_BF16;
     TailLn2 ln{res, gamma2, nullptr, nullptr, const_cast<float*>(mean2), const_cast<float*>(rstd2), dout2, f3, ds};
     const int lwgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
@@ -1120,7 +1091,7 @@ extern "C" int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const 
     if (bfl) hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, true, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln, TailUp{nullptr, 0.0f, 0});
     else hipLaunchKernelGGL((tail_bwd_lc_kernel<8, 12, false, true>), dim3(lwgs), dim3(RT), lds, st, nullptr, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, bfl, bfl, p_drop, seed, nullptr, ln, TailUp{nullptr, 0.0f, 0});
     SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd");
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(5 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, lwgs, 5, n, dgamma2, dbeta2);
+    if (dgamma != nullptr) hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(5 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, lwgs, 5, n, dgamma2, dbeta2);
     SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd(fold)");
     return 0;
 }

@@ -48,6 +48,8 @@ SIGNATURES = {
     "spv_add_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "spv_permut_table_words": [c_i, c_i],
+    "spv_tail_bwd_parts": [c_i],
+    "spv_gemm_tn_fold": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp],
     "spv_small_sl_supported": [c_i, c_i, c_i],
     "spv_small_sl_partial_floats": [c_i, c_i],
     "spv_small_sl_fwd": [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
@@ -88,7 +90,12 @@ SIGNATURES = {
 _RESTYPES = {"spv_last_error": ctypes.c_char_p, "spv_path_count": ctypes.c_longlong, "spv_rowop_partial_floats": c_i64, "spv_fnet_workspace_floats": c_i64,
              "spv_fnet_twiddle_floats": c_i64, "spv_tail_ln_partial_floats": c_i64, "spv_permut_table_words": c_i64, "spv_small_sl_partial_floats": c_i64,
              "spv_cross_entropy_workspace_floats": c_i64}
-_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_tail_ln_supported", "spv_tail_up_supported", "spv_small_sl_supported"}
+_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_tail_ln_supported", "spv_tail_up_supported", "spv_small_sl_supported", "spv_tail_bwd_parts"}
+
+class FoldJob(ctypes.Structure):
+    """spv_fold_job (include/spv.h): the fold of a tail backward's partial column sums, handed to spv_gemm_tn_fold"""
+    _fields_ = [("partials", c_vp), ("out", c_vp * 5), ("parts", c_i), ("nsum", c_i), ("n", c_i)]
+
 
 _lib = None
 # live kernel timing (bench.py's roofline pass): when set, every entry point that launches on a stream is bracketed with HIP

@@ -6,6 +6,7 @@ on a HIP device: a CPU tensor raises (there is deliberately no CPU / eager-PyTor
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import warnings
 import weakref
@@ -233,6 +234,7 @@ _WORK_MODELS = {
     "spv_gemm_nt_grouped_rows": lambda i: ("gemm_grouped_rows", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
     "spv_gemm_nt_pool_bwd": lambda i: ("gemm_pool_bwd", i[1:4], i[7], "mfma", 2.0 * i[1] * i[2] * i[3]),
     "spv_gemm_tn": lambda i: ("gemm_tn", i[0:3], BF16, "mfma", 2.0 * i[0] * i[1] * i[2]),
+    "spv_gemm_tn_fold": lambda i: ("gemm_tn", i[0:3], BF16, "mfma", 2.0 * i[0] * i[1] * i[2]),
     # read h [rows,n] + x [rows,k], write out [rows,n]
     "spv_spectre_tail_fwd": lambda i: ("tail_fwd", i[0:3], i[3], "hbm", i[0] * (2.0 * i[1] + i[2]) * _es(i[3])),
     # read dout, h; write dh [rows,n] and dx_pool [rows,k]
@@ -382,9 +384,27 @@ def join_side_stream():
         _side_keep.clear()
 
 
-def _weight_grad(dh, x, rows, n, k, sink=None):
+def _fold_rides(dtype, rows, n, k):
+    """the tail backward's fold can ride in this weight gradient's split-K reduce (bf16 TN path on the main stream)"""
+    return (dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0 and not os.environ.get("SPV_NO_FOLD_RIDE")
+            and not (_SIDE_STREAM and not _timing() and 2.0 * rows * n * k >= _SIDE_MIN_FLOPS))
+
+
+def _fold_job(partials, outs, rows, n):
+    job = _native.FoldJob()
+    job.partials = _p(partials)
+    for i, o in enumerate(outs):
+        job.out[i] = _p(o)
+    job.parts = _native.call("spv_tail_bwd_parts", rows)
+    job.nsum = len(outs)
+    job.n = n
+    return job
+
+
+def _weight_grad(dh, x, rows, n, k, sink=None, fold=None):
     """dW[n,k] = dh[rows,n]^T . x[rows,k], split-K over rows.  bf16: TN kernel straight from the row-major activations
-    (transposing LDS reads); fp32 (parity path): NT kernel over explicit transposes."""
+    (transposing LDS reads); fp32 (parity path): NT kernel over explicit transposes.  fold (a _fold_job, only when
+    _fold_rides): the same layer's dgamma / dbeta / dbias fold, run as extra workgroups of the split-K reduce."""
     dev = dh.device
     dw = _grad_buf(sink, (n, k), dev)
     tiles = ((n + 127) // 128) * ((k + 127) // 128)
@@ -402,7 +422,10 @@ def _weight_grad(dh, x, rows, n, k, sink=None):
             nonlocal ws
             if ws is None and splits > 1:
                 ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev)
-            _native.call("spv_gemm_tn", _p(dh), _p(x), _p(dw), n, k, rows, n, k, k, F32, 0, splits, _p(ws), _stream())
+            if fold is not None:
+                _native.call("spv_gemm_tn_fold", _p(dh), _p(x), _p(dw), n, k, rows, n, k, k, F32, 0, splits, _p(ws), ctypes.addressof(fold), _stream())
+            else:
+                _native.call("spv_gemm_tn", _p(dh), _p(x), _p(dw), n, k, rows, n, k, k, F32, 0, splits, _p(ws), _stream())
         if _SIDE_STREAM and not _timing() and 2.0 * rows * n * k >= _SIDE_MIN_FLOPS:
             # a big weight gradient (the MHPermutMix 8192 -> 512 linear: 279 GFLOP) has no consumer inside the backward
             # chain: run it on a second HIP stream so that it fills the ramp/tail gaps of the data-gradient GEMM and
@@ -498,15 +521,17 @@ def _sl_backward(dout2, saved, need_dx=True, dx_add=None, up=None):
     dbeta = _grad_buf(s_be, (n,), dev)
     dbias = _grad_buf(s_b, (n,), dev)
     partials = torch.empty((_native.call("spv_rowop_partial_floats", n),), dtype=torch.float32, device=dev)
+    ride = _fold_rides(dh.dtype, rows, n, k)  # the fold of the three column sums rides in the weight gradient's split-K reduce
+    pg, pb, pbi = (0, 0, 0) if ride else (_p(dgamma), _p(dbeta), _p(dbias))
     if up is not None:
         _native.call("spv_spectre_tail_bwd_up", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
-                     _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
+                     pg, pb, pbi, _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
                      _p(dx_add) if need_dx else 0, _p(up[0]), float(up[1]), int(up[2]), _stream())
     else:
         _native.call("spv_spectre_tail_bwd", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
-                     _p(dgamma), _p(dbeta), _p(dbias), _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
+                     pg, pb, pbi, _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
                      _p(dx_add) if need_dx else 0, _stream())
-    dw = _weight_grad(dh, x2, rows, n, k, s_w)  # side stream: overlaps the data gradient below
+    dw = _weight_grad(dh, x2, rows, n, k, s_w, _fold_job(partials, (dgamma, dbeta, dbias), rows, n) if ride else None)
     if need_dx:
         _gemm(dh, wt, None, dx, rows, k, n, n, wt.shape[1], k, accumulate=1)
     else:
@@ -1222,10 +1247,12 @@ class FFResidualFn(torch.autograd.Function):
             # linear3's skip gradient (its transposed pooling) is taken by linear1's tail backward from `ds` itself when the
             # shapes allow: df1 is then a plain GEMM output (no [rows, 768] tensor written here and re-read by the GEMM)
             defer = _native.call("spv_tail_up_supported", s1[9], s1[10], _dt(h3)) and s1[9] == k
-            _native.call("spv_spectre_tail_ln_bwd", _p(d2), _p(f3), _p(x1), _p(mean2), _p(rstd2), _p(n2w), _p(ds), _p(dn2w), _p(dn2b),
-                         _p(h3), _p(mean3), _p(rstd3), _p(g3), _p(be3), _p(dh3), 0 if defer else _p(df1), _p(dg3), _p(dbe3), _p(db3),
+            ride = _fold_rides(dh3.dtype, rows, n, k)   # the five column sums' fold rides in the weight gradient's split-K reduce
+            pp = (lambda t: 0) if ride else _p
+            _native.call("spv_spectre_tail_ln_bwd", _p(d2), _p(f3), _p(x1), _p(mean2), _p(rstd2), _p(n2w), _p(ds), pp(dn2w), pp(dn2b),
+                         _p(h3), _p(mean3), _p(rstd3), _p(g3), _p(be3), _p(dh3), 0 if defer else _p(df1), pp(dg3), pp(dbe3), pp(db3),
                          _p(partials), rows, n, k, _dt(h3), p_drop, seed, _stream())
-            dw3 = _weight_grad(dh3, f1, rows, n, k, s_w)
+            dw3 = _weight_grad(dh3, f1, rows, n, k, s_w, _fold_job(partials, (dg3, dbe3, db3, dn2w, dn2b), rows, n) if ride else None)
             _gemm(dh3, wt3, None, df1, rows, k, n, n, wt3.shape[1], k, accumulate=0 if defer else 1)
             if defer:
                 dx1, dw1, db1, dg1, dbe1 = _sl_backward(df1, s1, True, dx_add=ds, up=(ds, p_drop, seed))
