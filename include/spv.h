@@ -99,18 +99,23 @@ int spv_set_reserved_cus(int n);
  * ds_read_b64_tr_b16); M, N, lda, ldb multiples of 8; split-K as above. */
 int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
                 int accumulate, int splits, void* workspace, void* stream);
-/* The same, with the fold of a SpectreLinear tail backward's per-workgroup partial column sums riding in the split-K reduce launch
- * as extra workgroups: out[p][c] = sum_w partials[w][p][c], p < nsum <= 5 (dgamma, dbeta, dbias[, dgamma2, dbeta2]), c < n, fixed
- * order.  The tail backward is then called with its parameter-gradient pointers NULL (it writes the partials and launches no fold);
- * parts = spv_tail_bwd_parts(rows).  With splits == 1 the fold runs as its own launch. */
+/* The same, with up to six folds of row kernels' per-workgroup partial column sums riding in the split-K reduce launch as extra
+ * workgroups: out[p][c] = sum_w partials[w][p][c], p < nsum <= 5 (dgamma, dbeta, dbias[, dgamma2, dbeta2]), c < n, fixed order.
+ * The row kernel (spv_spectre_tail_bwd*, spv_spectre_tail_ln_bwd, spv_fnet_ln_bwd) is then called with its parameter-gradient
+ * pointers NULL: it writes the partials and launches no fold (parts = spv_tail_bwd_parts(rows) for the tails, batch for the FNet
+ * kernel).  With splits == 1 the folds run as one launch of their own.  Why: a 5-us launch between two large kernels costs the
+ * step ~20 us (eight per-layer fold launches removed: 157 us of 2.26 ms). */
 typedef struct spv_fold_job {
     const float* partials;
     float* out[5];
     int parts, nsum, n;
 } spv_fold_job;
 int spv_tail_bwd_parts(int rows);
+/* Folds with no reduce to ride in: up to any number of jobs in one launch per six (the end-of-backward flush of folds that were
+ * held back for a later spv_gemm_tn_fold which never came). */
+int spv_fold_multi(const spv_fold_job* folds, int nfolds, void* stream);
 int spv_gemm_tn_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
-                     int accumulate, int splits, void* workspace, const spv_fold_job* fold, void* stream);
+                     int accumulate, int splits, void* workspace, const spv_fold_job* folds, int nfolds, void* stream);
 
 /* ---- SpectreLinear tail: out = dropout(GELU_erf(LayerNorm(h)) + adaptive_avg_pool(x)) ---------
  * spectre_vit/models/spectre/layers.py:85-101 (LN eps 1e-5, nn.GELU exact, AdaptiveAvgPool1d over the

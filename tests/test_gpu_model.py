@@ -405,3 +405,46 @@ def test_mh_permut_mix_full_width_vs_oracle(dtype):
     check(m.linear.local_head[0].weight.grad, gr["linear"]["weight"], tol * 2, "dW")
     check(m.linear.local_head[1].weight.grad, gr["linear"]["ln_weight"], tol * 2, "dgamma")
     check(m.linear.local_head[0].bias.grad, gr["linear"]["bias"], tol * 2, "dbias")
+
+
+def test_held_folds_give_the_same_gradients():
+    """The FNet kernel's dgamma / dbeta fold is held back for the next weight-gradient reduce of the backward pass when its outputs are
+    GradReducer sink slots (hip_ops._hold_fold): every gradient must equal, bit for bit, the plain backward's (own fold launch, fresh
+    gradient tensors), nothing may stay held, and the holding must really have happened."""
+    from spectre_vit import hip_ops
+    from spectre_vit.dp import GradReducer
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    cfg = dict(img_size=32, patch_size=4, in_channels=3, num_classes=100, embed_dim=512, num_encoders=2, num_heads=16, hidden_dim=768,
+               dropout=0.0, activation="gelu", mixer="fft")
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(64, 3, 32, 32, generator=g).to(d)
+    labels = torch.randint(0, 100, (64,), generator=g).to(d)
+
+    def grads(with_sinks):
+        torch.manual_seed(9)
+        m = SpectreViT(**cfg).to(d).train()
+        red = GradReducer(m, always=True) if with_sinks else None
+        if red is not None:
+            red.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(img)
+        torch.nn.functional.cross_entropy(out, labels).backward()
+        if red is not None:
+            red.finish()
+        assert not hip_ops._held_folds
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    held = []
+    orig = hip_ops._hold_fold
+    hip_ops._hold_fold = lambda *a: (held.append(orig(*a)) or held[-1])
+    try:
+        plain = grads(False)
+        assert held and not any(held), held          # no sinks: never held
+        held.clear()
+        sunk = grads(True)
+        assert held and all(held), held              # sink slots: both layers' folds were held and carried by a later reduce
+    finally:
+        hip_ops._hold_fold = orig
+    for k in plain:
+        assert torch.equal(plain[k], sunk[k]), k

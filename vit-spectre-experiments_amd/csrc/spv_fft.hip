@@ -724,22 +724,12 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
     V2_STAMP_RT(11);
 }
 
-// dgamma / dbeta of the fused backward: out[c] = sum over workgroup slabs, 16 columns x 64 slab rows per workgroup
-__global__ __launch_bounds__(1024) void fnet_ln_fold_kernel(const float* __restrict__ partials, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int parts) {
-    __shared__ float red[64][17];
-    const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cx;  // < 2 * V2D
-    float s = 0.0f;
-    for (int w = py; w < parts; w += 64) s += partials[(size_t)w * 2 * V2D + c];
-    red[py][cx] = s;
-    __syncthreads();
-    if (py == 0) {
-        float t = 0.0f;
-        for (int q = 0; q < 64; ++q) t += red[q][cx];
-        if (c < V2D) dgamma[c] = t;
-        else dbeta[c - V2D] = t;
-    }
+// dgamma / dbeta of the fused backward: out[p][c] = sum over the per-sample slabs [batch][2][V2D], in the order every fold of this
+// library uses (spv_common.h fold_partials_block), so that a deferred fold (spv_reduce_multi) gives the same bits
+__global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void fnet_ln_fold_kernel(const float* __restrict__ partials, float* __restrict__ dgamma,
+                                                                            float* __restrict__ dbeta, int parts) {
+    const FoldJob j{partials, {dgamma, dbeta, nullptr, nullptr, nullptr}, parts, 2, V2D};
+    fold_partials_block(j, blockIdx.x, threadIdx.x);
 }
 
 // ---------------- generic fallback (any tokens, dim): two direct-DFT kernels through an fp32 workspace
@@ -1019,7 +1009,7 @@ extern "C" int spv_fnet_ln_bwd(const void* dout, const void* prenorm, const floa
                                int dtype, void* stream) {
     SPV_CHECK(batch > 0 && spv_fnet_ln_supported(tokens, dim, dtype), "spv_fnet_ln_bwd: unsupported shape %d x %d x %d / dtype %d", batch,
               tokens, dim, dtype);
-    SPV_CHECK(twiddle && gamma && mean && rstd && prenorm && dgamma && dbeta && partials, "spv_fnet_ln_bwd: null pointer");
+    SPV_CHECK(twiddle && gamma && mean && rstd && prenorm && partials && ((dgamma != nullptr) == (dbeta != nullptr)), "spv_fnet_ln_bwd: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     FnetLn ln{gamma, nullptr, const_cast<float*>(mean), const_cast<float*>(rstd), nullptr, nullptr, static_cast<const bf16_t*>(prenorm), partials};
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fnet_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1029,7 +1019,8 @@ extern "C" int spv_fnet_ln_bwd(const void* dout, const void* prenorm, const floa
                        static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dx), reinterpret_cast<const uint4*>(twiddle + v2_frag_off(tokens)),
                        reinterpret_cast<const uint4*>(twiddle + v2_extra_off(tokens)), twiddle + v2_tw_off(tokens), tokens, fnet_ln_stagger(batch), static_cast<const bf16_t*>(dout), ln);
     SPV_LAUNCH_CHECK("spv_fnet_ln_bwd");
-    hipLaunchKernelGGL(fnet_ln_fold_kernel, dim3(2 * V2D / 16), dim3(1024), 0, st, partials, dgamma, dbeta, batch);
+    // dgamma == NULL: the caller folds the partials itself (deferred: spv_reduce_multi kind 1 with parts = batch, nsum = 2, n = dim)
+    if (dgamma != nullptr) hipLaunchKernelGGL(fnet_ln_fold_kernel, dim3(2 * V2D / FOLD_COLS), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, batch);
     SPV_LAUNCH_CHECK("spv_fnet_ln_bwd(fold)");
     return 0;
 }

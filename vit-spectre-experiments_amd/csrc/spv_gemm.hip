@@ -1268,18 +1268,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     splitk_reduce_body<TO>(ws, bias, C, M, N, ldc, splits, accumulate, blockIdx.x, gridDim.x, threadIdx.x, 256);
 }
 
-// the split-K reduce of a weight gradient with the fold of the same layer's dgamma / dbeta / dbias partials as extra workgroups: the
-// fold launch of a tail backward (5.5 us at its floor, eight per step) rides along in a launch that happens anyway
+// Several folds in ONE launch (spv_fold_multi), and up to FJ_MAX folds riding in a split-K reduce (spv_gemm_tn_fold).  A 5-us launch
+// between two large kernels costs the step ~20 us (eight per-layer fold launches removed: 157 us), so folds travel with launches that
+// happen anyway.  (Keeping the split-K SUMS back until the end of the backward as well was measured and dropped: 2.09 -> 2.23 ms --
+// eight 33 MB workspaces outlive their stay in the 256 MB MALL and the late sum reads them from HBM.)
+constexpr int FJ_MAX = 6;
+struct FoldJobs {
+    int njobs;
+    int first_block[FJ_MAX + 1];
+    FoldJob job[FJ_MAX];
+};
+__device__ __forceinline__ void fold_jobs_block(const FoldJobs& fj, int bid, int tid) {
+    int j = 0;
+    while (j + 1 < fj.njobs && bid >= fj.first_block[j + 1]) ++j;   // workgroup-uniform
+    fold_partials_block(fj.job[j], bid - fj.first_block[j], tid);
+}
+__global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void fold_multi_kernel(FoldJobs fj) { fold_jobs_block(fj, blockIdx.x, threadIdx.x); }
+
+// the split-K reduce of a weight gradient with folds (the same layer's dgamma / dbeta / dbias partials, and any fold held back by an
+// earlier node of the backward) as extra workgroups
 template <typename TO>
 __global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void splitk_reduce_fold_kernel(const float* __restrict__ ws, TO* __restrict__ C, int M, int N,
                                                                                    int ldc, int splits, int accumulate, int reduce_blocks,
-                                                                                   FoldJob job) {
+                                                                                   FoldJobs fj) {
     if ((int)blockIdx.x < reduce_blocks)
         splitk_reduce_body<TO>(ws, nullptr, C, M, N, ldc, splits, accumulate, blockIdx.x, reduce_blocks, threadIdx.x, FOLD_COLS * FOLD_ROWS);
     else
-        fold_partials_block(job, (int)blockIdx.x - reduce_blocks, threadIdx.x);
+        fold_jobs_block(fj, (int)blockIdx.x - reduce_blocks, threadIdx.x);
 }
-__global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void fold_only_kernel(FoldJob job) { fold_partials_block(job, blockIdx.x, threadIdx.x); }
 
 inline int kend_len(int K, int k_per_split) { return K < k_per_split ? K : k_per_split; }
 
@@ -1427,8 +1443,26 @@ static int gemm_entry(const void* A, const void* B, const float* bias, void* C, 
     return launch_gemm<float, float>(A, B, bias, C, M, N, K, lda, ldb, ldc, accumulate, splits, workspace, st, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
 }
 
+static int fill_fold_jobs(const spv_fold_job* folds, int nfolds, FoldJobs& fj, int& blocks) {
+    fj.njobs = nfolds;
+    blocks = 0;
+    for (int i = 0; i < nfolds; ++i) {
+        const spv_fold_job& f = folds[i];
+        if (f.partials == nullptr || f.parts <= 0 || f.nsum < 1 || f.nsum > 5 || f.n <= 0 || f.out[0] == nullptr) return -1;
+        fj.first_block[i] = blocks;
+        fj.job[i].partials = f.partials;
+        for (int u = 0; u < 5; ++u) fj.job[i].o[u] = u < f.nsum ? f.out[u] : nullptr;
+        fj.job[i].parts = f.parts;
+        fj.job[i].np = f.nsum;
+        fj.job[i].n = f.n;
+        blocks += cdiv((int64_t)f.nsum * f.n, FOLD_COLS);
+    }
+    fj.first_block[nfolds] = blocks;
+    return 0;
+}
+
 static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
-                        int accumulate, int splits, void* workspace, void* stream, const spv_fold_job* fold) {
+                        int accumulate, int splits, void* workspace, void* stream, const spv_fold_job* folds, int nfolds) {
     SPV_COUNT_PATH(SPV_PATH_GEMM_TN);
     SPV_CHECK(M > 0 && N > 0 && K > 0, "spv_gemm_tn: empty problem M=%d N=%d K=%d", M, N, K);
     SPV_CHECK(out_dtype == SPV_F32 || out_dtype == SPV_BF16, "spv_gemm_tn: bad out_dtype %d", out_dtype);
@@ -1493,27 +1527,20 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
 #undef SPV_TN
     SPV_LAUNCH_CHECK("spv_gemm_tn");
     }
-    FoldJob job{};
+    FoldJobs fj{};
     int fold_blocks = 0;
-    if (fold != nullptr) {
-        SPV_CHECK(fold->partials != nullptr && fold->parts > 0 && fold->nsum >= 1 && fold->nsum <= 5 && fold->n > 0, "spv_gemm_tn_fold: bad fold job");
-        job.partials = fold->partials;
-        for (int i = 0; i < 5; ++i) job.o[i] = i < fold->nsum ? fold->out[i] : nullptr;
-        job.parts = fold->parts;
-        job.np = fold->nsum;
-        job.n = fold->n;
-        fold_blocks = cdiv((int64_t)fold->nsum * fold->n, FOLD_COLS);
-    }
+    SPV_CHECK(nfolds >= 0 && nfolds <= FJ_MAX && (nfolds == 0 || folds != nullptr), "spv_gemm_tn_fold: 0..%d fold jobs", FJ_MAX);
+    SPV_CHECK(fill_fold_jobs(folds, nfolds, fj, fold_blocks) == 0, "spv_gemm_tn_fold: bad fold job");
     if (splits > 1) {
         if (fold_blocks > 0) {
             constexpr int RT1 = FOLD_COLS * FOLD_ROWS;
             const int blocks = (int)std::min<int64_t>(((int64_t)M * N / ((N & 3) == 0 ? 4 : 1) + RT1 - 1) / RT1, 1024);
             if (out_dtype == SPV_BF16)
                 hipLaunchKernelGGL((splitk_reduce_fold_kernel<bf16_t>), dim3(blocks + fold_blocks), dim3(RT1), 0, st, ws, (bf16_t*)C, M, N, ldc, splits,
-                                   accumulate, blocks, job);
+                                   accumulate, blocks, fj);
             else
                 hipLaunchKernelGGL((splitk_reduce_fold_kernel<float>), dim3(blocks + fold_blocks), dim3(RT1), 0, st, ws, (float*)C, M, N, ldc, splits,
-                                   accumulate, blocks, job);
+                                   accumulate, blocks, fj);
             SPV_LAUNCH_CHECK("spv_gemm_tn_fold(split-k reduce + fold)");
             return 0;
         }
@@ -1527,7 +1554,7 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
         SPV_LAUNCH_CHECK("spv_gemm_tn(split-k reduce)");
     }
     if (fold_blocks > 0 && splits <= 1) {   // no reduce to ride on: the fold runs by itself
-        hipLaunchKernelGGL(fold_only_kernel, dim3(fold_blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, job);
+        hipLaunchKernelGGL(fold_multi_kernel, dim3(fold_blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, fj);
         SPV_LAUNCH_CHECK("spv_gemm_tn_fold(fold)");
     }
     return 0;
@@ -1535,11 +1562,23 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
 
 extern "C" int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
                            int accumulate, int splits, void* workspace, void* stream) {
-    return gemm_tn_impl(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, accumulate, splits, workspace, stream, nullptr);
+    return gemm_tn_impl(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, accumulate, splits, workspace, stream, nullptr, 0);
 }
 
 extern "C" int spv_gemm_tn_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
-                                int accumulate, int splits, void* workspace, const spv_fold_job* fold, void* stream) {
-    return gemm_tn_impl(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, accumulate, splits, workspace, stream, fold);
+                                int accumulate, int splits, void* workspace, const spv_fold_job* folds, int nfolds, void* stream) {
+    return gemm_tn_impl(A, B, C, M, N, K, lda, ldb, ldc, out_dtype, accumulate, splits, workspace, stream, folds, nfolds);
 }
 
+extern "C" int spv_fold_multi(const spv_fold_job* folds, int nfolds, void* stream) {
+    SPV_CHECK(folds != nullptr && nfolds > 0, "spv_fold_multi: no jobs");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int j0 = 0; j0 < nfolds; j0 += FJ_MAX) {
+        FoldJobs fj{};
+        int blocks = 0;
+        SPV_CHECK(fill_fold_jobs(folds + j0, std::min(FJ_MAX, nfolds - j0), fj, blocks) == 0, "spv_fold_multi: bad fold job");
+        hipLaunchKernelGGL(fold_multi_kernel, dim3(blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, fj);
+        SPV_LAUNCH_CHECK("spv_fold_multi");
+    }
+    return 0;
+}

@@ -49,7 +49,8 @@ SIGNATURES = {
     "spv_permut_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "spv_permut_table_words": [c_i, c_i],
     "spv_tail_bwd_parts": [c_i],
-    "spv_gemm_tn_fold": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_vp],
+    "spv_fold_multi": [c_vp, c_i, c_vp],
+    "spv_gemm_tn_fold": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_i, c_vp],
     "spv_small_sl_supported": [c_i, c_i, c_i],
     "spv_small_sl_partial_floats": [c_i, c_i],
     "spv_small_sl_fwd": [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],

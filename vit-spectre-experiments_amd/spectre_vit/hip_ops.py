@@ -384,6 +384,57 @@ def join_side_stream():
         _side_keep.clear()
 
 
+# ------------------------------------------------------------------------------------------------
+# folds travel with launches that happen anyway: a row kernel's fold of its partial column sums (dgamma / dbeta / dbias) either rides
+# in its own layer's weight-gradient reduce (_sl_backward) or -- the FNet kernel has no GEMM beside it -- is held back for the next
+# weight-gradient reduce of the same backward pass; whatever is still held when the autograd engine finishes runs as one launch.
+# Held folds need gradient memory that outlives the node (a GradReducer sink): autograd would otherwise copy the unfinished tensor.
+# With data parallelism the bucket hooks need every gradient as soon as its node has run: nothing is held.
+# ------------------------------------------------------------------------------------------------
+_held_folds = []   # (partials, outputs, parts, n)
+FOLD_RIDERS = 6    # fold jobs one reduce launch carries (csrc/spv_gemm.hip FJ_MAX)
+
+
+def _hold_ok():
+    if os.environ.get("SPV_NO_HOLD") or _timing():
+        return False
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
+def _fold_array(folds):
+    arr = (_native.FoldJob * len(folds))()
+    for j, (partials, outs, parts, n) in zip(arr, folds):
+        j.partials = _p(partials)
+        for i, o in enumerate(outs):
+            j.out[i] = o if isinstance(o, int) else _p(o)   # held folds carry raw sink addresses (see _hold_fold)
+        j.parts, j.nsum, j.n = parts, len(outs), n
+    return arr
+
+
+def flush_held_folds():
+    """run the folds still held (called by the autograd engine when the backward pass is over)"""
+    if _held_folds:
+        arr = _fold_array(_held_folds)
+        _native.call("spv_fold_multi", ctypes.addressof(arr), len(_held_folds), _stream())
+        _held_folds.clear()
+
+
+def _hold_fold(partials, outs, sinks, parts, n):
+    """hold a fold for the next weight-gradient reduce of this backward pass.  Only when every output IS its parameter's sink slot
+    (memory that outlives the node; autograd adopts the alias without copying), and never by keeping the output tensors themselves:
+    a second reference makes AccumulateGrad clone the -- still unfolded -- gradient.  False (not held) otherwise."""
+    if not _hold_ok() or any(sk is None or o.data_ptr() != sk.view.data_ptr() for o, sk in zip(outs, sinks)):
+        return False
+    if not _held_folds:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_held_folds)
+        except RuntimeError:   # not inside a backward pass
+            return False
+    _held_folds.append((partials, tuple(o.data_ptr() for o in outs), parts, n))
+    return True
+
+
 def _fold_rides(dtype, rows, n, k):
     """the tail backward's fold can ride in this weight gradient's split-K reduce (bf16 TN path on the main stream)"""
     return (dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0 and not os.environ.get("SPV_NO_FOLD_RIDE")
@@ -391,14 +442,9 @@ def _fold_rides(dtype, rows, n, k):
 
 
 def _fold_job(partials, outs, rows, n):
-    job = _native.FoldJob()
-    job.partials = _p(partials)
-    for i, o in enumerate(outs):
-        job.out[i] = _p(o)
-    job.parts = _native.call("spv_tail_bwd_parts", rows)
-    job.nsum = len(outs)
-    job.n = n
-    return job
+    """(partials, outputs, partial slabs, row length): the fold of a tail backward's column sums, to ride in / be deferred with the
+    weight gradient's reduction"""
+    return (partials, tuple(outs), _native.call("spv_tail_bwd_parts", rows), n)
 
 
 def _weight_grad(dh, x, rows, n, k, sink=None, fold=None):
@@ -418,12 +464,18 @@ def _weight_grad(dh, x, rows, n, k, sink=None, fold=None):
         splits = max(1, min(256 // tiles, rows // 64))
     ws = None
     if dh.dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0:
-        def launch():
+        def launch(riders=True):
             nonlocal ws
             if ws is None and splits > 1:
                 ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev)
-            if fold is not None:
-                _native.call("spv_gemm_tn_fold", _p(dh), _p(x), _p(dw), n, k, rows, n, k, k, F32, 0, splits, _p(ws), ctypes.addressof(fold), _stream())
+            folds = [fold] if fold is not None else []
+            if riders:
+                while _held_folds and len(folds) < FOLD_RIDERS:
+                    folds.append(_held_folds.pop(0))
+            if folds:
+                arr = _fold_array(folds)
+                _native.call("spv_gemm_tn_fold", _p(dh), _p(x), _p(dw), n, k, rows, n, k, k, F32, 0, splits, _p(ws), ctypes.addressof(arr),
+                             len(folds), _stream())
             else:
                 _native.call("spv_gemm_tn", _p(dh), _p(x), _p(dw), n, k, rows, n, k, k, F32, 0, splits, _p(ws), _stream())
         if _SIDE_STREAM and not _timing() and 2.0 * rows * n * k >= _SIDE_MIN_FLOPS:
@@ -435,7 +487,7 @@ def _weight_grad(dh, x, rows, n, k, sink=None, fold=None):
             side = _side_stream(dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                launch()  # allocates its split-K workspace from the side stream's pool
+                launch(False)  # allocates its split-K workspace from the side stream's pool; held folds stay with the main stream
             _side_keep.append((dh, x, ws, dw))
         else:
             launch()
@@ -1308,8 +1360,11 @@ class FNetResidualFn(torch.autograd.Function):
             dn1b = _grad_buf(sinks[1], (D,), dev)
             partials = torch.empty((B * 2 * D,), dtype=torch.float32, device=dev)
             tw = _fnet_twiddle(N, dev)
-            _native.call("spv_fnet_ln_bwd", _p(d2), _p(m), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dn1w), _p(dn1b), _p(partials),
-                         _p(tw), B, N, D, _dt(m), _stream())
+            # the fold of the per-sample column sums travels with the next weight-gradient reduce (the layer below's); only into
+            # sink memory -- a fresh tensor would be copied by autograd before the fold has run
+            held = _hold_fold(partials, (dn1w, dn1b), sinks, B, D)
+            _native.call("spv_fnet_ln_bwd", _p(d2), _p(m), _p(mean), _p(rstd), _p(gamma), _p(dx), 0 if held else _p(dn1w),
+                         0 if held else _p(dn1b), _p(partials), _p(tw), B, N, D, _dt(m), _stream())
             return dx, dn1w, dn1b
         dm, dn1w, dn1b = _addln_backward(d2, sn)
         dx = _fnet_raw(dm.reshape(B, N, D), add_in=d2)  # symmetric operator; + the residual gradient, folded in
