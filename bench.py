@@ -173,6 +173,7 @@ class Job:
             from spectre_vit.loss import CrossEntropyLoss
             self.crit = CrossEntropyLoss()
         self.use_bf16 = args.dtype == "bf16" and not stand_in
+        self.one = torch.ones((), dtype=torch.float32, device=dev)
         self.dev = dev
         self.param_bytes = sum(p.numel() for p in model.parameters()) * 4
         self.timer = None
@@ -183,7 +184,7 @@ class Job:
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_bf16):
             out = self.model(self.img)
         loss = self.crit(out, self.labels)
-        loss.backward()
+        loss.backward(self.one)   # a kept 1.0: backward() without it fills a fresh one every step (a launch)
         self.reducer.finish()
         if self.timer is not None and isinstance(self.opt, torch.optim.AdamW):  # fused AdamW reads p, g, m, v and writes p, m, v
             self.timer.bracket("torch:adamw_fused", (7 * self.param_bytes,), self.opt.step)

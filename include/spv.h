@@ -294,6 +294,13 @@ int spv_spectral_fold_bwd(const float* dw_full, const float* proj_w, const float
                           float* dproj_w, float* dfreq_h, float* dfreq_w, float* scratch, int embed, int chans,
                           int patch, void* stream);
 int spv_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+/* Backward of the token tensor in one pass + one fold: dtok = dropout_mask(g [+ gcls on the CLS rows]) (the mask of the forward's
+ * spv_dropout with the same seed over the same flat index; dtok may be NULL when it would equal g), and the sums over the batch that
+ * dpos [tokens][embed], dbias[e] = sum_{t >= 1} dpos[t][e] and dcls[e] = dpos[0][e] are (gradients of position_embeddings, proj.bias
+ * and cls_token, spectre.py:133-135,150-155).  partials: spv_embed_bwd_groups(batch) * tokens * embed floats. */
+int spv_embed_bwd_groups(int batch);
+int spv_embed_bwd(const void* g, const void* gcls, void* dtok, float* partials, float* dpos, float* dbias, float* dcls, int batch,
+                  int tokens, int embed, float p_drop, uint64_t seed, int dtype, void* stream);
 
 /* ---- softmax attention core for the baseline ViT ------------------------------------------------
  * nn.MultiheadAttention inside the stock nn.TransformerEncoderLayer, spectre_vit/models/vit/vit.py:30-38:

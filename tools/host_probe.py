@@ -26,7 +26,8 @@ def main():
     from spectre_vit.optim import FusedAdamW
     reducer = GradReducer(model, always=True)
     opt = FusedAdamW(model.parameters(), lr=1e-3, static_grads=True)
-    crit = torch.nn.CrossEntropyLoss()
+    from spectre_vit.loss import CrossEntropyLoss
+    crit = CrossEntropyLoss()
 
     def step():
         reducer.zero_grad()

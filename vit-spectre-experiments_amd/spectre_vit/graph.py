@@ -39,6 +39,7 @@ class GraphedTrainStep:
         self.seed_word = torch.zeros(1, dtype=torch.int64, device=dev)
         _native.call("spv_set_seed_device_ptr", self.seed_word.data_ptr())
         self._st = None
+        one = torch.ones((), dtype=torch.float32, device=dev)
 
         def one_step():
             _native.call("spv_seed_advance", self.seed_word.data_ptr(), torch.cuda.current_stream().cuda_stream)
@@ -46,7 +47,7 @@ class GraphedTrainStep:
             with torch.autocast("cuda", dtype=self.autocast_dtype, enabled=self.autocast_dtype is not None):
                 out = self.model(self.img)
             loss = self.criterion(out, self.labels)
-            loss.backward()
+            loss.backward(one)   # a kept 1.0 (backward() alone fills a fresh one: a launch per step)
             self.reducer.finish()
             self.optimizer.step()
             return loss, out

@@ -816,13 +816,23 @@ class SpectralFoldFn(torch.autograd.Function):
         return dw, dfh, dfw, None, None
 
 
+class _EmbedKey:
+    """identity of one PatchEmbedFn node (its output tensor carries it; TapClsFn stashes the CLS-row gradient under it)"""
+    __slots__ = ("__weakref__",)
+
+
+_cls_grad_stash = weakref.WeakKeyDictionary()
+
+
 class PatchEmbedFn(torch.autograd.Function):
     """tokens[b,0] = cls + pos[0]; tokens[b,1+n] = W_full . patch(b,n) + bias + pos[1+n]."""
 
     @staticmethod
-    def forward(ctx, img, w_full, bias, cls, pos, patch, dtype, norm=None):
+    def forward(ctx, img, w_full, bias, cls, pos, patch, dtype, norm=None, p_drop=0.0):
         """img: float NCHW (the reference's input contract), or -- SURVEY 8f-3 -- the loader's uint8 NHWC batch with
-        norm = (mean[C], inv_std[C]) device tensors: /255 + Normalize are then folded into the patch gather."""
+        norm = (mean[C], inv_std[C]) device tensors: /255 + Normalize are then folded into the patch gather.
+        p_drop: the nn.Dropout that follows the embedding (reference spectre.py:156), kept inside this node so that its backward,
+        the CLS-row gradient of the global residual and the three column sums are one pass over the token gradient."""
         _require_gpu(img, w_full)
         u8 = img.dtype == torch.uint8
         if u8:
@@ -853,34 +863,47 @@ class PatchEmbedFn(torch.autograd.Function):
         tokens = torch.empty((B, T, E), dtype=dtype, device=dev)
         _native.call("spv_gemm_nt_grouped_rows", _p(patches), _p(wc), 0, _p(posbias), _p(tokens), B * T, E, K, K, K, E,
                      _DT[dtype], _DT[dtype], T, T, 0, st)
+        seed = 0
+        if p_drop > 0.0:
+            seed = _new_seed()
+            dropped = torch.empty_like(tokens)
+            _native.call("spv_dropout", _p(tokens), _p(dropped), tokens.numel(), float(p_drop), seed, _dt(tokens), st)
+            tokens = dropped
         # bf16: the backward's TN weight-gradient GEMM reads the patch matrix as it lies here (3 MB), so keep it
         ctx.save_for_backward(None if u8 else img, patches if (dtype == torch.bfloat16 or u8) else None)
-        ctx.meta = (B, C, H, W, patch, E, K, Np, T, dtype, cls.shape, pos.shape)
+        ctx.meta = (B, C, H, W, patch, E, K, Np, T, dtype, cls.shape, pos.shape, float(p_drop), seed)
         ctx.sinks = (_sink(bias), _sink(cls), _sink(pos))
+        ctx.key = _EmbedKey()   # TapClsFn hands the CLS-row gradient of the global residual to this node's backward under this key
+        tokens._spv_embed_key = ctx.key
         return tokens
 
     @staticmethod
     def backward(ctx, dtok):
         img, patches = ctx.saved_tensors
-        B, C, H, W, patch, E, K, Np, T, dtype, cls_shape, pos_shape = ctx.meta
+        B, C, H, W, patch, E, K, Np, T, dtype, cls_shape, pos_shape, p_drop, seed = ctx.meta
         dev = dtok.device
         st = _stream()
         dtok = dtok.contiguous()
-        part = torch.empty((min(B, 512) * T * E,), dtype=torch.float32, device=dev)
+        gcls = _cls_grad_stash.pop(ctx.key, None)   # (B, E): the global residual's CLS-row gradient, not yet added (TapClsFn)
+        if gcls is not None:
+            gcls = gcls.to(dtok.dtype).contiguous()
         s_bias, s_cls, s_pos = ctx.sinks
         dpos_full = _grad_buf(s_pos, pos_shape, dev)  # straight into the data-parallel bucket / the optimizer's fixed gradient slot
-        dpos = dpos_full.view(T, E)
-        _native.call("spv_colsum", _p(dtok), _p(dpos), _p(part), B, T * E, _dt(dtok), st)
         dbias = _grad_buf(s_bias, (E,), dev)
-        _native.call("spv_colsum", _p(dpos[1:]), _p(dbias), _p(part), T - 1, E, F32, st)
         dcls = _grad_buf(s_cls, cls_shape, dev)
-        dcls.view(-1).copy_(dpos[0])
+        part = torch.empty((_native.call("spv_embed_bwd_groups", B) * T * E,), dtype=torch.float32, device=dev)
+        # one pass: + CLS-row gradient, dropout mask, the batch sums of the three parameter gradients; then their fold
+        masked = torch.empty_like(dtok) if (gcls is not None or p_drop > 0.0) else None
+        _native.call("spv_embed_bwd", _p(dtok), _p(gcls), _p(masked), _p(part), _p(dpos_full), _p(dbias), _p(dcls), B, T, E, p_drop, seed,
+                     _dt(dtok), st)
+        if masked is not None:
+            dtok = masked
         if patches is not None and dtok.dtype == torch.bfloat16:
             # dW = dtok^T . P over all B*T token rows, with P the patch matrix widened by a zero row per image (the CLS
             # row): the TN kernel then takes dtok as it lies in memory -- no transposed copies of a 34 MB tensor
             dwf = _weight_grad(dtok.view(B * T, E), patches, B * T, E, K)
             join_side_stream()
-            return None, dwf, dbias, dcls, dpos_full, None, None, None
+            return None, dwf, dbias, dcls, dpos_full, None, None, None, None
         rows = B * Np
         ld = (rows + 7) // 8 * 8
         dyt = torch.empty((E, ld), dtype=dtok.dtype, device=dev)
@@ -895,7 +918,7 @@ class PatchEmbedFn(torch.autograd.Function):
         splits = max(1, min(1024 // tiles, (ld + 511) // 512))
         ws = torch.empty((splits * E * K,), dtype=torch.float32, device=dev) if splits > 1 else None
         _gemm(dyt, pt, None, dwf, E, K, ld, ld, ld, K, 0, splits, ws)
-        return None, dwf, dbias, dcls, dpos_full, None, None, None
+        return None, dwf, dbias, dcls, dpos_full, None, None, None, None
 
 
 # CIFAR-100 statistics of the reference loader (spectre_vit/repl/train.py:109-112)
@@ -925,13 +948,13 @@ class PixelNorm:
         return PixelNorm(self.mean, self.std)
 
 
-def patch_embed(x, w_full, bias, cls, pos, patch, pixel_norm):
-    """float NCHW or uint8 NHWC images -> token tensor (B, 1 + patches, E)."""
+def patch_embed(x, w_full, bias, cls, pos, patch, pixel_norm, p_drop=0.0):
+    """float NCHW or uint8 NHWC images -> token tensor (B, 1 + patches, E) [-> dropout(p_drop)]."""
     if x.dtype == torch.uint8:
         dt = torch.bfloat16 if torch.is_autocast_enabled("cuda") else torch.float32
         norm = pixel_norm.tensors(x.device, x.shape[-1])
-        return PatchEmbedFn.apply(x, w_full, bias, cls, pos, patch, dt, norm)
-    return PatchEmbedFn.apply(x, w_full, bias, cls, pos, patch, compute_dtype(x))
+        return PatchEmbedFn.apply(x, w_full, bias, cls, pos, patch, dt, norm, float(p_drop))
+    return PatchEmbedFn.apply(x, w_full, bias, cls, pos, patch, compute_dtype(x), None, float(p_drop))
 
 
 class DropoutFn(torch.autograd.Function):
@@ -985,6 +1008,7 @@ class TapClsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         _require_gpu(x)
+        ctx.key = getattr(x, "_spv_embed_key", None)   # x is a PatchEmbedFn output: its backward adds the CLS rows in its own pass
         return x.view_as(x), x[:, 0, :]   # a strided view: the class head reads the CLS rows where they lie
 
     @staticmethod
@@ -993,6 +1017,9 @@ class TapClsFn(torch.autograd.Function):
             return gx
         if gx is None:
             raise RuntimeError("TapClsFn: the layer stack produced no input gradient")
+        if ctx.key is not None:
+            _cls_grad_stash[ctx.key] = gcls
+            return gx
         if not gx.is_contiguous():
             gx = gx.contiguous()
         gx[:, 0, :] += gcls.to(gx.dtype)  # in place: this edge owns the tensor (it was written for it by the first layer's backward)

@@ -148,8 +148,8 @@ class SpectralPatchEmbed(nn.Module):
     def forward(self, x):
         C = x.shape[-1] if x.dtype == torch.uint8 else x.shape[1]
         w_full = hip_ops.SpectralFoldFn.apply(self.proj.weight, self.freq_weight_h, self.freq_weight_w, C, self.P)
-        tok = hip_ops.patch_embed(x, w_full, self.proj.bias, self.cls_token, self.position_embeddings, self.P, self.pixel_norm)
-        return hip_ops.dropout(tok, self.dropout.p, self.training)
+        return hip_ops.patch_embed(x, w_full, self.proj.bias, self.cls_token, self.position_embeddings, self.P, self.pixel_norm,
+                                   self.dropout.p if self.training else 0.0)   # the nn.Dropout of spectre.py:156, inside the same node
 
 
 class SpectreViT(nn.Module):
