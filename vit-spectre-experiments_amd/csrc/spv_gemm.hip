@@ -1291,10 +1291,13 @@ template <typename TO>
 __global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void splitk_reduce_fold_kernel(const float* __restrict__ ws, TO* __restrict__ C, int M, int N,
                                                                                    int ldc, int splits, int accumulate, int reduce_blocks,
                                                                                    FoldJobs fj) {
-    if ((int)blockIdx.x < reduce_blocks)
-        splitk_reduce_body<TO>(ws, nullptr, C, M, N, ldc, splits, accumulate, blockIdx.x, reduce_blocks, threadIdx.x, FOLD_COLS * FOLD_ROWS);
+    // the folds first: their workgroups are the long ones (a column of up to 1024 partial rows each), the sums' are many and short
+    const int fold_blocks = fj.first_block[fj.njobs];
+    if ((int)blockIdx.x < fold_blocks)
+        fold_jobs_block(fj, (int)blockIdx.x, threadIdx.x);
     else
-        fold_jobs_block(fj, (int)blockIdx.x - reduce_blocks, threadIdx.x);
+        splitk_reduce_body<TO>(ws, nullptr, C, M, N, ldc, splits, accumulate, blockIdx.x - fold_blocks, reduce_blocks, threadIdx.x,
+                               FOLD_COLS * FOLD_ROWS);
 }
 
 inline int kend_len(int K, int k_per_split) { return K < k_per_split ? K : k_per_split; }
@@ -1534,7 +1537,7 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
     if (splits > 1) {
         if (fold_blocks > 0) {
             constexpr int RT1 = FOLD_COLS * FOLD_ROWS;
-            const int blocks = (int)std::min<int64_t>(((int64_t)M * N / ((N & 3) == 0 ? 4 : 1) + RT1 - 1) / RT1, 1024);
+            const int blocks = (int)std::min<int64_t>(((int64_t)M * N / ((N & 3) == 0 ? 4 : 1) + RT1 - 1) / RT1, 2048);
             if (out_dtype == SPV_BF16)
                 hipLaunchKernelGGL((splitk_reduce_fold_kernel<bf16_t>), dim3(blocks + fold_blocks), dim3(RT1), 0, st, ws, (bf16_t*)C, M, N, ldc, splits,
                                    accumulate, blocks, fj);

@@ -254,7 +254,7 @@ extern "C" int spv_embed_cls_rows(const float* cls, const float* pos, void* toke
 // ---- backward of the token tensor, one pass: dtok = dropout_mask(g [+ gcls on the CLS rows]) and the column sums over the batch
 // that the position / bias / class-token gradients are made of.  (Separately this was a strided add, a dropout pass, a column-sum
 // pass and three small folds over a 34 MB tensor: seven launches.)  grid = (column blocks of 8-element vectors, groups of EB_GS samples).
-constexpr int EB_GS = 8;
+constexpr int EB_GS = 16, EB_HB = 8;   // samples per workgroup row-group; loads in flight per thread
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(const T* __restrict__ g, const T* __restrict__ gcls, T* __restrict__ dtok,
                                                             float* __restrict__ partials, int B, int TE, int E, float p, uint64_t seed) {
@@ -268,45 +268,47 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(const T* __restrict
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
     const bool cls_row = gcls != nullptr && col < E;
-    // all EB_GS rows' loads are issued before the first is used (clamped addresses, masked sums): one row per trip was a chain of
-    // HBM round trips (25 us for 68 MB)
-    float x[EB_GS][8], c[EB_GS][8];
+    // EB_HB rows' loads are issued before the first is used (clamped addresses, masked sums): one row per trip was a chain of HBM
+    // round trips (25 us for 68 MB)
+    for (int h0 = 0; h0 < EB_GS; h0 += EB_HB) {
+        float x[EB_HB][8], c[EB_HB][8];
 #pragma unroll
-    for (int s = 0; s < EB_GS; ++s) {
-        const int b = min(b0 + s, B - 1);
-        const size_t i = (size_t)b * TE + col;
-        io<T>::ld4(g + i, *reinterpret_cast<float(*)[4]>(&x[s][0]));
-        io<T>::ld4(g + i + 4, *reinterpret_cast<float(*)[4]>(&x[s][4]));
-        if (cls_row) {   // block-uniform for all but one block
-            io<T>::ld4(gcls + (size_t)b * E + col, *reinterpret_cast<float(*)[4]>(&c[s][0]));
-            io<T>::ld4(gcls + (size_t)b * E + col + 4, *reinterpret_cast<float(*)[4]>(&c[s][4]));
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < EB_GS; ++s) {
-        const int b = b0 + s;
-        if (b >= B) break;
-        const size_t i = (size_t)b * TE + col;
-        if (cls_row) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[s][u] += c[s][u];
-        }
-        if (p > 0.0f) {
-            const unsigned key = dropout_row_key(sd, (uint64_t)i >> 12);
-            const unsigned c0 = (unsigned)(i & 4095);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[s][u] *= dropout_scale(key, c0 + u, p, inv_keep);
-        }
-        if (sizeof(T) == 2) {   // the sums are taken over what the weight-gradient GEMM reads: the rounded values
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[s][u] = bf2f(f2bf(x[s][u]));
-        }
-        if (dtok != nullptr) {
-            io<T>::st4(dtok + i, *reinterpret_cast<const float(*)[4]>(&x[s][0]));
-            io<T>::st4(dtok + i + 4, *reinterpret_cast<const float(*)[4]>(&x[s][4]));
+        for (int s = 0; s < EB_HB; ++s) {
+            const int b = min(b0 + h0 + s, B - 1);
+            const size_t i = (size_t)b * TE + col;
+            io<T>::ld4(g + i, *reinterpret_cast<float(*)[4]>(&x[s][0]));
+            io<T>::ld4(g + i + 4, *reinterpret_cast<float(*)[4]>(&x[s][4]));
+            if (cls_row) {   // block-uniform for all but one block
+                io<T>::ld4(gcls + (size_t)b * E + col, *reinterpret_cast<float(*)[4]>(&c[s][0]));
+                io<T>::ld4(gcls + (size_t)b * E + col + 4, *reinterpret_cast<float(*)[4]>(&c[s][4]));
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] += x[s][u];
+        for (int s = 0; s < EB_HB; ++s) {
+            const int b = b0 + h0 + s;
+            if (b >= B) break;
+            const size_t i = (size_t)b * TE + col;
+            if (cls_row) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[s][u] += c[s][u];
+            }
+            if (p > 0.0f) {
+                const unsigned key = dropout_row_key(sd, (uint64_t)i >> 12);
+                const unsigned c0 = (unsigned)(i & 4095);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[s][u] *= dropout_scale(key, c0 + u, p, inv_keep);
+            }
+            if (sizeof(T) == 2) {   // the sums are taken over what the weight-gradient GEMM reads: the rounded values
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[s][u] = bf2f(f2bf(x[s][u]));
+            }
+            if (dtok != nullptr) {
+                io<T>::st4(dtok + i, *reinterpret_cast<const float(*)[4]>(&x[s][0]));
+                io<T>::st4(dtok + i + 4, *reinterpret_cast<const float(*)[4]>(&x[s][4]));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += x[s][u];
+        }
     }
     float* po = partials + (size_t)blockIdx.y * TE + col;
     *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -323,14 +325,13 @@ __global__ __launch_bounds__(1024) void embed_bwd_fold_kernel(const float* __res
     if (e < E) {
         for (int t = py; t < T; t += 64) {
             float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-            int w = 0;
-            for (; w + 4 <= groups; w += 4) {
-                s0 += partials[((size_t)w * T + t) * E + e];
-                s1 += partials[((size_t)(w + 1) * T + t) * E + e];
-                s2 += partials[((size_t)(w + 2) * T + t) * E + e];
-                s3 += partials[((size_t)(w + 3) * T + t) * E + e];
+            for (int w0 = 0; w0 < groups; w0 += 16) {   // sixteen independent loads in flight
+                float q[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) q[j] = partials[((size_t)min(w0 + j, groups - 1) * T + t) * E + e] * (w0 + j < groups ? 1.0f : 0.0f);
+#pragma unroll
+                for (int j = 0; j < 16; j += 4) { s0 += q[j]; s1 += q[j + 1]; s2 += q[j + 2]; s3 += q[j + 3]; }
             }
-            for (; w < groups; ++w) s0 += partials[((size_t)w * T + t) * E + e];
             const float v = (s0 + s1) + (s2 + s3);
             dpos[(size_t)t * E + e] = v;
             if (t == 0) dcls[e] = v;
