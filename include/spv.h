@@ -83,6 +83,11 @@ int spv_gemm_nt(const void* A, const void* B, const float* bias, void* C, int M,
 int spv_gemm_nt_grouped_rows(const void* A, const void* B, const float* bias, const float* bias2d, void* C, int M,
                              int N, int K, int lda, int ldb, int ldc, int in_dtype, int out_dtype,
                              int rows_per_group, int group_stride, int row_offset, void* stream);
+/* The same with the dropout that follows the projection (spectre.py:156) applied in the epilogue: the mask of spv_dropout /
+ * spv_embed_bwd for the same seed over the flat index of the (contiguous, ldc == N) output. */
+int spv_gemm_nt_grouped_rows_drop(const void* A, const void* B, const float* bias, const float* bias2d, void* C, int M, int N, int K,
+                                  int lda, int ldb, int ldc, int in_dtype, int out_dtype, int rows_per_group, int group_stride,
+                                  int row_offset, float p_drop, uint64_t seed, void* stream);
 
 /* Data gradient of a SpectreLinear whose skip pools exact windows (in = pool_window * out, the MHPermutMix linear,
  * layers.py:66,93): C[M,N] = A[M,K] . B[N,K]^T + dout[M, N/pool_window][.., n / pool_window] / pool_window -- the

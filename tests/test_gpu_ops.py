@@ -773,3 +773,33 @@ def test_fold_rides_in_the_split_k_reduce(ops, monkeypatch, rows, n, k):
     plain = run()
     for a, c, name in zip(rode, plain, ("dx", "dW", "dbias", "dgamma", "dbeta")):
         assert torch.equal(a, c), name
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embedding_dropout_in_the_gemm_epilogue_matches_the_dropout_kernel(ops, dtype):
+    """PatchEmbedFn with p > 0: the mask applied in the token GEMM's epilogue must be the one spv_dropout draws from the same seed on
+    the flat token index (and the backward's spv_embed_bwd re-derives): compare with the unfused composition bit for bit."""
+    from spectre_vit import _native
+    B, C, H, P, E = 6, 3, 32, 4, 64
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(B, C, H, H, generator=g).to(dev())
+    K = C * P * P
+    w_full = (torch.randn(E, K, generator=g) / K ** 0.5).to(dev())
+    bias, cls = torch.randn(E, generator=g).to(dev()), torch.randn(1, 1, E, generator=g).to(dev())
+    T = (H // P) ** 2 + 1
+    pos = torch.randn(1, T, E, generator=g).to(dev())
+    base = ops.PatchEmbedFn.apply(img, w_full, bias, cls, pos, P, dtype, None, 0.0)
+    calls = []
+    orig = ops._new_seed
+    ops._new_seed = lambda: (calls.append(1) or 12345)
+    try:
+        fused = ops.PatchEmbedFn.apply(img, w_full, bias, cls, pos, P, dtype, None, 0.25)
+    finally:
+        ops._new_seed = orig
+    ref = torch.empty_like(base)
+    _native.call("spv_dropout", base.data_ptr(), ref.data_ptr(), base.numel(), 0.25, 12345, 1 if dtype == torch.bfloat16 else 0,
+                 torch.cuda.current_stream().cuda_stream)
+    kept = (fused != 0).float().mean().item()
+    assert abs(kept - 0.75) < 0.02, kept
+    assert torch.equal(fused == 0, ref == 0)
+    torch.testing.assert_close(fused.float(), ref.float(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-6)

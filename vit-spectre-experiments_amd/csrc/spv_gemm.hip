@@ -11,6 +11,7 @@
 // Global -> registers -> LDS staging with the next tile's loads issued before the MFMAs of the current
 // one (one barrier pair per K step).  bf16: v_mfma_f32_32x32x16_bf16; fp32: v_mfma_f32_32x32x2_f32
 // (exact fp32 fma chain -- the parity path).
+#define SPV_USES_SEED
 #include "spv_common.h"
 
 #include <stdlib.h>
@@ -68,7 +69,8 @@ __device__ __forceinline__ void store_acc_tile(f32x16 (*acc)[2], unsigned char* 
                                                TO* __restrict__ C, float* __restrict__ ws, int M, int N, int ldc, int accumulate,
                                                int m0, int n0, int split, int rg, int gs, int roff,
                                                const float* __restrict__ bias2d, const void* __restrict__ bc = nullptr,
-                                               int bc_pw = 0, int bc_bf = 0, int wrow = -1, int wcol = -1) {
+                                               int bc_pw = 0, int bc_bf = 0, int wrow = -1, int wcol = -1, float drop_p = 0.0f,
+                                               uint64_t drop_seed = 0) {
     // acc: two rows of two 32x32 accumulators = this wave's 64 x 64 block at tile rows wrow.. (default (wave >> 1) * 64)
     // and tile columns wcol.. (default (wave & 1) * 64)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -149,6 +151,16 @@ __device__ __forceinline__ void store_acc_tile(f32x16 (*acc)[2], unsigned char* 
 #pragma unroll
                     for (int u = 0; u < 8; ++u) v[u] += b2[u];
                 }
+                if (drop_p > 0.0f) {
+                    // the nn.Dropout that follows the projection (spectre.py:156), on the flat index of the contiguous output: the
+                    // mask spv_dropout / spv_embed_bwd derive from the same seed
+                    const size_t fi = (size_t)orow * ldc + col0;
+                    const unsigned key = dropout_row_key(live_seed(drop_seed), (uint64_t)fi >> 12);
+                    const unsigned c0 = (unsigned)(fi & 4095);
+                    const float inv_keep = 1.0f / (1.0f - drop_p);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] *= dropout_scale(key, c0 + u, drop_p, inv_keep);
+                }
                 if constexpr (sizeof(TO) == 2) {
                     if (accumulate) {
                         const uint4 old = *reinterpret_cast<const uint4*>(cp);
@@ -177,6 +189,10 @@ __device__ __forceinline__ void store_acc_tile(f32x16 (*acc)[2], unsigned char* 
                     float x = v[u];
                     if (bias != nullptr) x += bias[col0 + u];
                     if (b2 != nullptr) x += b2[u];
+                    if (drop_p > 0.0f) {
+                        const size_t fi = (size_t)orow * ldc + col0 + u;
+                        x *= dropout_scale(dropout_row_key(live_seed(drop_seed), (uint64_t)fi >> 12), (unsigned)(fi & 4095), drop_p, 1.0f / (1.0f - drop_p));
+                    }
                     if (accumulate) x += load_out<TO>(cp + u);
                     store_out<TO>(cp + u, x);
                 }
@@ -192,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
                                                       int ldb, int ldc, int k_per_split, int accumulate,
                                                       int tiles_n, int tiles_mn, int nsplit, int rg, int gs, int roff,
                                                       const float* __restrict__ bias2d, const void* __restrict__ bc, int bc_pw,
-                                                      int bc_bf) {
+                                                      int bc_bf, float drop_p, uint64_t drop_seed) {
     constexpr int BK = KT<T>::BK;
     constexpr int CH = KT<T>::CH;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * ROWB];
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const T* __restrict__ A, c
         __syncthreads();
     }
 
-    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
+    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d, bc, bc_pw, bc_bf, -1, -1, drop_p, drop_seed);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -324,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
                                                            int ldc, int k_per_split, int accumulate, int tiles_n,
                                                            int tiles_mn, int nsplit, int rg, int gs, int roff,
                                                            const float* __restrict__ bias2d, const void* __restrict__ bc,
-                                                           int bc_pw, int bc_bf) {
+                                                           int bc_pw, int bc_bf, float drop_p, uint64_t drop_seed) {
     constexpr int CPR = KB / 16;              // 16-byte chunks per tile row
     constexpr int RPI = 64 / CPR;             // tile rows written by one wave instruction (1 KiB)
     constexpr int IPW = (BM / RPI) / 4;       // DMA instructions per wave per operand per stage
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(256) void gemm_nt_glds_kernel(const bf16_t* __restr
         }
         buf = (buf + 1 == NST) ? 0 : buf + 1;
     }
-    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
+    store_acc_tile<TO>(acc, smem, bias, C, ws, M, N, ldc, accumulate, m0, n0, split, rg, gs, roff, bias2d, bc, bc_pw, bc_bf, -1, -1, drop_p, drop_seed);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1302,6 +1318,10 @@ __global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void splitk_reduce_fold_kern
 
 inline int kend_len(int K, int k_per_split) { return K < k_per_split ? K : k_per_split; }
 
+// dropout of the grouped-rows epilogue (spv_gemm_nt_grouped_rows_drop sets them around its call; 0 everywhere else)
+static thread_local float t_drop_p = 0.0f;
+static thread_local uint64_t t_drop_seed = 0;
+
 template <typename T, typename TO>
 int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb,
                 int ldc, int accumulate, int splits, void* workspace, hipStream_t st, int rg = 0, int gs = 0, int roff = 0,
@@ -1319,7 +1339,7 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
         int mb, nstrips, groups, base, rem;
         const bool bc_ok = bc == nullptr || (bc_bf && !accumulate && bc_pw % 8 == 0 && N % bc_pw == 0);
         const bool span32 = (size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldb * 2 < (1ull << 32);  // 32-bit DMA source offsets
-        if (splits == 1 && rg == 0 && bias2d == nullptr && bc_ok && span32 && ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+        if (splits == 1 && rg == 0 && bias2d == nullptr && t_drop_p == 0.0f && bc_ok && span32 && ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
             (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 3) == 0) && strip_plan(M, N, K, mb, nstrips, groups, base, rem)) {
             const int nwg = groups * nstrips;
 #define SPV_STRIP(MBV, EPIV)                                                                                                \
@@ -1363,18 +1383,18 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
             if (kb == 64)
                 hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 64, 3>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                    static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                                   accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
+                                   accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf, t_drop_p, t_drop_seed);
             else
                 hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 128, 2>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                    static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                                   accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
+                                   accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf, t_drop_p, t_drop_seed);
             SPV_LAUNCH_CHECK("spv_gemm_nt(glds)");
             goto reduce;
         }
     }
     hipLaunchKernelGGL((gemm_nt_kernel<T, TO>), grid, dim3(256), 0, st, static_cast<const T*>(A),
                        static_cast<const T*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
-                       accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf);
+                       accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf, t_drop_p, t_drop_seed);
     SPV_LAUNCH_CHECK("spv_gemm_nt");
 reduce:
     if (splits > 1) {
@@ -1421,6 +1441,23 @@ extern "C" int spv_gemm_nt_grouped_rows(const void* A, const void* B, const floa
     return gemm_entry(A, B, bias, C, M, N, K, lda, ldb, ldc, in_dtype, out_dtype, 0, 1, nullptr, stream, rows_per_group,
                       group_stride, row_offset, bias2d);
 }
+
+extern "C" int spv_gemm_nt_grouped_rows_drop(const void* A, const void* B, const float* bias, const float* bias2d, void* C, int M,
+                                             int N, int K, int lda, int ldb, int ldc, int in_dtype, int out_dtype,
+                                             int rows_per_group, int group_stride, int row_offset, float p_drop, uint64_t seed,
+                                             void* stream) {
+    SPV_CHECK(p_drop >= 0.0f && p_drop < 1.0f, "spv_gemm_nt_grouped_rows_drop: p_drop=%f", p_drop);
+    SPV_CHECK(p_drop == 0.0f || ldc == N, "spv_gemm_nt_grouped_rows_drop: the mask is taken on the flat index of a contiguous output (ldc == N)");
+    t_drop_p = p_drop;
+    t_drop_seed = seed;
+    const int rc = spv_gemm_nt_grouped_rows(A, B, bias, bias2d, C, M, N, K, lda, ldb, ldc, in_dtype, out_dtype, rows_per_group, group_stride,
+                                            row_offset, stream);
+    t_drop_p = 0.0f;
+    t_drop_seed = 0;
+    return rc;
+}
+
+int spv_seed_ptr_set_gemm(const unsigned long long* p) { return spv_seed_symbol_set(p); }
 
 static int gemm_entry(const void* A, const void* B, const float* bias, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                       int in_dtype, int out_dtype, int accumulate, int splits, void* workspace, void* stream, int rg, int gs,

@@ -416,12 +416,13 @@ extern "C" int spv_adamw_multi(const void* table, const int* chunk_tensor, const
 int spv_seed_ptr_set_rowops(const unsigned long long* p);
 int spv_seed_ptr_set_patch(const unsigned long long* p);
 int spv_seed_ptr_set_attn(const unsigned long long* p);
+int spv_seed_ptr_set_gemm(const unsigned long long* p);
 namespace {
 __global__ void seed_advance_kernel(unsigned long long* p) { *p += 0x9e3779b97f4a7c15ull; }
 }
 extern "C" int spv_set_seed_device_ptr(const void* seed_word) {
     const unsigned long long* p = static_cast<const unsigned long long*>(seed_word);
-    SPV_CHECK(spv_seed_ptr_set_rowops(p) == 0 && spv_seed_ptr_set_patch(p) == 0 && spv_seed_ptr_set_attn(p) == 0,
+    SPV_CHECK(spv_seed_ptr_set_rowops(p) == 0 && spv_seed_ptr_set_patch(p) == 0 && spv_seed_ptr_set_attn(p) == 0 && spv_seed_ptr_set_gemm(p) == 0,
               "spv_set_seed_device_ptr: hipMemcpyToSymbol failed");
     return 0;
 }

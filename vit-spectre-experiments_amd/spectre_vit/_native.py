@@ -32,6 +32,7 @@ SIGNATURES = {
     "spv_weight_shadows_multi": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "spv_gemm_nt": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "spv_gemm_nt_grouped_rows": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "spv_gemm_nt_grouped_rows_drop": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],
     "spv_set_reserved_cus": [c_i],
     "spv_gemm_tn": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp],
     "spv_spectre_tail_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],

@@ -232,6 +232,7 @@ _WORK_MODELS = {
     "spv_cross_entropy_bwd": lambda i: ("cross_entropy_bwd", i[0:2], F32, "hbm", i[0] * i[1] * 8.0),
     "spv_gemm_nt": lambda i: ("gemm_acc" if i[8] else "gemm", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
     "spv_gemm_nt_grouped_rows": lambda i: ("gemm_grouped_rows", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
+    "spv_gemm_nt_grouped_rows_drop": lambda i: ("gemm_grouped_rows", i[0:3], i[6], "mfma", 2.0 * i[0] * i[1] * i[2]),
     "spv_gemm_nt_pool_bwd": lambda i: ("gemm_pool_bwd", i[1:4], i[7], "mfma", 2.0 * i[1] * i[2] * i[3]),
     "spv_gemm_tn": lambda i: ("gemm_tn", i[0:3], BF16, "mfma", 2.0 * i[0] * i[1] * i[2]),
     "spv_gemm_tn_fold": lambda i: ("gemm_tn", i[0:3], BF16, "mfma", 2.0 * i[0] * i[1] * i[2]),
@@ -861,14 +862,10 @@ class PatchEmbedFn(torch.autograd.Function):
         posbias = torch.empty((T, E), dtype=torch.float32, device=dev)
         _native.call("spv_embed_posbias", _p(pos), _p(bias), _p(cls), _p(posbias), Np, E, st)
         tokens = torch.empty((B, T, E), dtype=dtype, device=dev)
-        _native.call("spv_gemm_nt_grouped_rows", _p(patches), _p(wc), 0, _p(posbias), _p(tokens), B * T, E, K, K, K, E,
-                     _DT[dtype], _DT[dtype], T, T, 0, st)
-        seed = 0
-        if p_drop > 0.0:
-            seed = _new_seed()
-            dropped = torch.empty_like(tokens)
-            _native.call("spv_dropout", _p(tokens), _p(dropped), tokens.numel(), float(p_drop), seed, _dt(tokens), st)
-            tokens = dropped
+        seed = _new_seed() if p_drop > 0.0 else 0
+        # the dropout rides in the GEMM's epilogue (the mask spv_dropout would draw from the same seed; the backward re-derives it)
+        _native.call("spv_gemm_nt_grouped_rows_drop", _p(patches), _p(wc), 0, _p(posbias), _p(tokens), B * T, E, K, K, K, E,
+                     _DT[dtype], _DT[dtype], T, T, 0, float(p_drop), seed, st)
         # bf16: the backward's TN weight-gradient GEMM reads the patch matrix as it lies here (3 MB), so keep it
         ctx.save_for_backward(None if u8 else img, patches if (dtype == torch.bfloat16 or u8) else None)
         ctx.meta = (B, C, H, W, patch, E, K, Np, T, dtype, cls.shape, pos.shape, float(p_drop), seed)
