@@ -295,6 +295,9 @@ int spv_embed_cls_rows(const float* cls, const float* pos, void* tokens, int bat
                        int dtype, void* stream);
 int spv_spectral_fold(const float* proj_w, const float* freq_h, const float* freq_w, float* w_full, int embed,
                       int chans, int patch, void* stream);
+/* spv_spectral_fold that also writes the bf16 copy the token GEMM reads in a bf16 step (one launch instead of fold + cast) */
+int spv_spectral_fold_bf16(const float* proj_w, const float* freq_h, const float* freq_w, float* w_full, void* w_full_bf16, int embed,
+                           int chans, int patch, void* stream);
 int spv_spectral_fold_bwd(const float* dw_full, const float* proj_w, const float* freq_h, const float* freq_w,
                           float* dproj_w, float* dfreq_h, float* dfreq_w, float* scratch, int embed, int chans,
                           int patch, void* stream);

@@ -165,7 +165,8 @@ __device__ __forceinline__ float rcoef(int u, int v, int p, int q, int P) {
 
 // W_full[e][c,p,q] = sum_{u,v} W[e][c,u,v] fh[u] fw[v] R[(u,v),(p,q)]
 __global__ __launch_bounds__(256) void spectral_fold_kernel(const float* __restrict__ w, const float* __restrict__ fh,
-                                                            const float* __restrict__ fw, float* __restrict__ wf, int E, int C, int P) {
+                                                            const float* __restrict__ fw, float* __restrict__ wf, int E, int C, int P,
+                                                            bf16_t* __restrict__ wf_bf = nullptr) {
     const int Pv = P / 2 + 1;
     const int total = E * C * P * P;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void spectral_fold_kernel(const float* __restr
         for (int u = 0; u < P; ++u)
             for (int v = 0; v < Pv; ++v) a = fmaf(wr[u * Pv + v] * fh[u] * fw[v], rcoef(u, v, p, q, P), a);
         wf[i] = a;
+        if (wf_bf != nullptr) wf_bf[i] = f2bf(a);   // the GEMM operand of a bf16 step: saves the cast launch that followed
     }
 }
 
@@ -427,6 +429,15 @@ extern "C" int spv_spectral_fold(const float* proj_w, const float* freq_h, const
     hipLaunchKernelGGL(spectral_fold_kernel, dim3(ew_blocks((int64_t)embed * chans * patch * patch)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), proj_w, freq_h, freq_w, w_full, embed, chans, patch);
     SPV_LAUNCH_CHECK("spv_spectral_fold");
+    return 0;
+}
+
+extern "C" int spv_spectral_fold_bf16(const float* proj_w, const float* freq_h, const float* freq_w, float* w_full, void* w_full_bf16, int embed,
+                                      int chans, int patch, void* stream) {
+    SPV_CHECK(embed > 0 && chans > 0 && patch > 0 && w_full_bf16 != nullptr, "spv_spectral_fold_bf16: bad arguments");
+    hipLaunchKernelGGL(spectral_fold_kernel, dim3(ew_blocks((int64_t)embed * chans * patch * patch)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), proj_w, freq_h, freq_w, w_full, embed, chans, patch, static_cast<bf16_t*>(w_full_bf16));
+    SPV_LAUNCH_CHECK("spv_spectral_fold_bf16");
     return 0;
 }
 

@@ -78,6 +78,7 @@ SIGNATURES = {
     "spv_embed_posbias": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_vp],
     "spv_embed_cls_rows": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_spectral_fold": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "spv_spectral_fold_bf16": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "spv_spectral_fold_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "spv_dropout": [c_vp, c_vp, c_i64, c_f, c_u64, c_i, c_vp],
     "spv_attention_fwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_f, c_u64, c_vp],

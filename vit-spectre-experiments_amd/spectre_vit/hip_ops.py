@@ -797,7 +797,12 @@ class SpectralFoldFn(torch.autograd.Function):
         _require_gpu(proj_w)
         E = proj_w.shape[0]
         wf = torch.empty((E, chans * patch * patch), dtype=torch.float32, device=proj_w.device)
-        _native.call("spv_spectral_fold", _p(proj_w), _p(fh), _p(fw), _p(wf), E, chans, patch, _stream())
+        if torch.is_autocast_enabled("cuda"):   # a bf16 step: the token GEMM's operand comes out of the same launch (PatchEmbedFn picks it up)
+            wb = torch.empty(wf.shape, dtype=torch.bfloat16, device=proj_w.device)
+            _native.call("spv_spectral_fold_bf16", _p(proj_w), _p(fh), _p(fw), _p(wf), _p(wb), E, chans, patch, _stream())
+            wf._spv_bf16 = wb
+        else:
+            _native.call("spv_spectral_fold", _p(proj_w), _p(fh), _p(fw), _p(wf), E, chans, patch, _stream())
         ctx.save_for_backward(proj_w, fh, fw)
         ctx.sinks = (_sink(proj_w), _sink(fh), _sink(fw))
         ctx.meta = (E, chans, patch)
@@ -858,7 +863,9 @@ class PatchEmbedFn(torch.autograd.Function):
             _native.call("spv_patchify_u8", _p(img), _p(norm[0]), _p(norm[1]), _p(patches), B, C, H, W, patch, K, 2, _DT[dtype], st)
         else:
             _native.call("spv_patchify", _p(img), _p(patches), B, C, H, W, patch, K, 2, _DT[dtype], st)
-        wc = w_full if dtype == torch.float32 else _raw_cast(w_full, dtype)
+        wc = w_full if dtype == torch.float32 else (getattr(w_full, "_spv_bf16", None) if dtype == torch.bfloat16 else None)
+        if wc is None:
+            wc = _raw_cast(w_full, dtype)
         posbias = torch.empty((T, E), dtype=torch.float32, device=dev)
         _native.call("spv_embed_posbias", _p(pos), _p(bias), _p(cls), _p(posbias), Np, E, st)
         tokens = torch.empty((B, T, E), dtype=dtype, device=dev)
