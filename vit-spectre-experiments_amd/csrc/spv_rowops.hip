@@ -523,6 +523,106 @@ __global__ __launch_bounds__(RT) void addln_bwd_kernel(const void* __restrict__ 
     write_partials<VEC, MAXI, 2>(acc, lds, partials + (size_t)blockIdx.x * 2 * n, n, lane, wave);
 }
 
+// The same for rows of exactly MAXI * 256 elements (the encoder widths 512 / 768 / 1024), dtype and mode compile-time facts, and the
+// NEXT row's loads kept in flight RAW: the generic kernel converts inside the branch that loaded (run-time dtype flag), which puts an
+// s_waitcnt behind every load -- 37 us for the 136 MB of a Small layer (0.35 of HBM peak) where the tails reach 0.6-0.7.
+template <int MAXI, bool BF, int MODE>
+__global__ __launch_bounds__(RT) void addln_bwd_fast_kernel(const void* __restrict__ dout, const void* __restrict__ a,
+                                                             const void* __restrict__ b, const float* __restrict__ mean_i,
+                                                             const float* __restrict__ rstd_i, const float* __restrict__ gamma,
+                                                             void* __restrict__ din, float* __restrict__ partials, int rows) {
+    constexpr int VEC = 4, n = MAXI * 256;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wave_g = blockIdx.x * RW + wave;
+    const int nwaves = gridDim.x * RW;
+    float acc[2][MAXI][VEC];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) acc[p][i][k] = 0.0f;
+    struct RawRow { uint4 a[MAXI], b[MAXI], d[MAXI]; float m, r; };
+    auto ld1 = [&](const void* p, size_t idx) -> uint4 {
+        if constexpr (BF) {
+            const uint2 t = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(p) + idx);
+            return make_uint4(t.x, t.y, 0u, 0u);
+        } else {
+            return *reinterpret_cast<const uint4*>(static_cast<const float*>(p) + idx);
+        }
+    };
+    auto un = [&](const uint4& r, float (&o)[4]) {
+        if constexpr (BF) {
+            o[0] = __uint_as_float(r.x << 16); o[1] = __uint_as_float(r.x & 0xffff0000u);
+            o[2] = __uint_as_float(r.y << 16); o[3] = __uint_as_float(r.y & 0xffff0000u);
+        } else {
+            o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+        }
+    };
+    auto fetch = [&](int row, RawRow& f) {
+        f.m = mean_i[row];
+        f.r = rstd_i[row];
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const size_t idx = (size_t)row * n + (i * 64 + lane) * VEC;
+            f.a[i] = ld1(a, idx);
+            if constexpr (MODE == 1) f.b[i] = ld1(b, idx);
+            f.d[i] = ld1(dout, idx);
+        }
+    };
+    float g[MAXI][VEC];
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i) {
+        const float4 t = *reinterpret_cast<const float4*>(gamma + (i * 64 + lane) * VEC);
+        g[i][0] = t.x; g[i][1] = t.y; g[i][2] = t.z; g[i][3] = t.w;
+    }
+    RawRow cur;
+    if (wave_g < rows) fetch(wave_g, cur);
+    for (int row = wave_g; row < rows; row += nwaves) {
+        RawRow nxt = cur;
+        const int nrow = row + nwaves;
+        if (nrow < rows) fetch(nrow, nxt);
+        const float mean = cur.m, rstd = cur.r;
+        float xh[MAXI][VEC], dxh[MAXI][VEC];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            float av[4], dv[4];
+            un(cur.a[i], av);
+            un(cur.d[i], dv);
+            if constexpr (MODE == 1) {
+                float bv[4];
+                un(cur.b[i], bv);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) av[k] += bv[k];
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                const float xhat = (av[k] - mean) * rstd;
+                acc[0][i][k] += dv[k] * xhat;
+                acc[1][i][k] += dv[k];
+                const float t = dv[k] * g[i][k];
+                xh[i][k] = xhat;
+                dxh[i][k] = t;
+                s1 += t;
+                s2 += t * xhat;
+            }
+        }
+        const float m1 = wave_sum(s1) * (1.0f / (float)n), m2 = wave_sum(s2) * (1.0f / (float)n);
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            float o[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) o[k] = rstd * (dxh[i][k] - m1 - xh[i][k] * m2);
+            stv<VEC>(din, (size_t)row * n + (i * 64 + lane) * VEC, BF, o);
+        }
+        cur = nxt;
+    }
+    write_partials<VEC, MAXI, 2>(acc, lds, partials + (size_t)blockIdx.x * 2 * n, n, lane, wave);
+}
+
 // out[p][c] = sum_w partials[w][p][c]; a workgroup of 1024 threads owns 16 columns (64-byte segments), 64 thread rows
 // split the slabs (<= 16 loads each at 1024 slabs: the kernel is latency bound, so the loads must be spread thin),
 // fixed summation order
@@ -1120,8 +1220,26 @@ extern "C" int spv_add_layernorm_bwd(const void* dout, const void* a, const void
     SPV_CHECK(pick_cfg(n, cfg), "spv_add_layernorm_bwd: unsupported row length %d", n);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int wgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
-    ROW_DISPATCH(cfg, addln_bwd_kernel, dim3(wgs), (size_t)2 * n * sizeof(float), st, dout, a, b, mean, rstd, gamma, din,
-                 partials, rows, n, mode, dtype == SPV_BF16);
+    static const bool no_fast = getenv("SPV_ADDLN_GENERIC") != nullptr;   // A/B switch
+    const bool aligned16 = (((uintptr_t)dout | (uintptr_t)a | (uintptr_t)(b ? b : a) | (uintptr_t)din | (uintptr_t)gamma) & 15) == 0;
+    if (!no_fast && aligned16 && (n == 512 || n == 768 || n == 1024)) {
+        const size_t lds = (size_t)2 * n * sizeof(float);
+        const bool bf = dtype == SPV_BF16;
+#define SPV_ADDLN_FAST(MI)                                                                                                                 \
+    do {                                                                                                                                   \
+        if (bf && mode == 1) hipLaunchKernelGGL((addln_bwd_fast_kernel<MI, true, 1>), dim3(wgs), dim3(RT), lds, st, dout, a, b, mean, rstd, gamma, din, partials, rows);   \
+        else if (bf) hipLaunchKernelGGL((addln_bwd_fast_kernel<MI, true, 0>), dim3(wgs), dim3(RT), lds, st, dout, a, b, mean, rstd, gamma, din, partials, rows);           \
+        else if (mode == 1) hipLaunchKernelGGL((addln_bwd_fast_kernel<MI, false, 1>), dim3(wgs), dim3(RT), lds, st, dout, a, b, mean, rstd, gamma, din, partials, rows);   \
+        else hipLaunchKernelGGL((addln_bwd_fast_kernel<MI, false, 0>), dim3(wgs), dim3(RT), lds, st, dout, a, b, mean, rstd, gamma, din, partials, rows);                  \
+    } while (0)
+        if (n == 512) SPV_ADDLN_FAST(2);
+        else if (n == 768) SPV_ADDLN_FAST(3);
+        else SPV_ADDLN_FAST(4);
+#undef SPV_ADDLN_FAST
+    } else {
+        ROW_DISPATCH(cfg, addln_bwd_kernel, dim3(wgs), (size_t)2 * n * sizeof(float), st, dout, a, b, mean, rstd, gamma, din,
+                     partials, rows, n, mode, dtype == SPV_BF16);
+    }
     SPV_LAUNCH_CHECK("spv_add_layernorm_bwd");
     hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(2 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, (float*)nullptr, wgs, 2, n);
     SPV_LAUNCH_CHECK("spv_add_layernorm_bwd(fold)");
