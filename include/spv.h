@@ -177,6 +177,16 @@ int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const void* res, 
  * mode 1: out = LN(a + b)      norm2(x + ff(x))    spectre.py:67
  * backward returns d(LN input) in `din` and dgamma/dbeta; the residual gradient of mode 0's `b`
  * is dout itself. */
+/* One-level Haar DWT along the embedding axis + LayerNorm-1 + residual as one row kernel each way (bf16, dim 512 or 1024):
+ * out = LN(haar(x)) * gamma + beta + x -- SpectreEncoderLayer's norm1(mix(x)) + x (spectre.py:66) with the 'dwt_embed' mixer of
+ * BASELINE config 3 (repl/dwt_experiments.py:56).  Same values as spv_haar_dwt followed by spv_add_layernorm_fwd(mode 0), the bf16
+ * rounding of the band tensor between them included; the backward recomputes haar(x) from x, nothing of the mixer is stored.
+ * dgamma == NULL: the caller folds `partials` (parts = spv_tail_bwd_parts(rows), nsum = 2, n = dim). */
+int spv_haar_ln_supported(int dim, int dtype);
+int spv_haar_ln_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd, int rows, int dim,
+                    int dtype, void* stream);
+int spv_haar_ln_bwd(const void* dout, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                    float* dgamma, float* dbeta, float* partials, int rows, int dim, int dtype, void* stream);
 int spv_add_layernorm_fwd(const void* a, const void* b, const float* gamma, const float* beta, void* out,
                           float* mean, float* rstd, int rows, int n, int mode, int dtype, void* stream);
 int spv_add_layernorm_bwd(const void* dout, const void* a, const void* b, const float* mean,

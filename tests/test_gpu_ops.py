@@ -803,3 +803,43 @@ def test_embedding_dropout_in_the_gemm_epilogue_matches_the_dropout_kernel(ops, 
     assert abs(kept - 0.75) < 0.02, kept
     assert torch.equal(fused == 0, ref == 0)
     torch.testing.assert_close(fused.float(), ref.float(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,D", [(4, 65, 512), (3, 7, 1024), (512, 65, 512)])
+def test_haar_ln_residual_fused_vs_unfused_and_oracle(ops, B, N, D):
+    """HaarResidualFn (one row kernel each way) vs the composition it replaces -- HaarDWTFn + add_layernorm(mode 0) -- and vs the
+    float64 oracle: out = LN(haar(x)) * gamma + beta + x, dx, dgamma, dbeta.  bf16 storage on both sides."""
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(B + D)
+    x = torch.randn(B, N, D, generator=g).to(dev()).to(bf)
+    gam = (torch.rand(D, generator=g) + 0.5).to(dev())
+    bet = (torch.randn(D, generator=g) * 0.1).to(dev())
+    dy = torch.randn(B, N, D, generator=g).to(dev()).to(bf)
+
+    def run(fused):
+        xi = x.clone().requires_grad_(True)
+        gi, bi = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+        if fused:
+            y = ops.HaarResidualFn.apply(xi, gi, bi)
+        else:
+            y = ops.add_layernorm(ops.HaarDWTFn.apply(xi, 2, 1), xi, gi, bi, 0)
+        y.backward(dy)
+        return y, xi.grad, gi.grad, bi.grad
+
+    assert ops.haar_ln_ok(x, "embed", 1)
+    yf, dxf, dgf, dbf = run(True)
+    yu, dxu, dgu, dbu = run(False)
+    # against the unfused kernels: same arithmetic up to the summation order of the statistics and one rounding less in dx
+    check(yf, n64(yu), 1e-2, "out vs unfused")
+    check(dxf, n64(dxu), 1.5e-2, "dx vs unfused")
+    check(dgf, n64(dgu), 2e-3, "dgamma vs unfused")
+    check(dbf, n64(dbu), 2e-3, "dbeta vs unfused")
+    if B * N <= 1000:   # oracle (float64) on the small cases
+        xs = n64(x)
+        m = O.haar_dwt_fwd(xs, axis=-1, levels=1)
+        ln, cache = O.layernorm_fwd(m, n64(gam), n64(bet))
+        check(yf, ln + xs, 2e-2, "out vs oracle")
+        dm, dg64, db64 = O.layernorm_bwd(n64(dy), n64(gam), cache)
+        check(dxf, O.haar_dwt_bwd(dm, axis=-1, levels=1) + n64(dy), 3e-2, "dx vs oracle")
+        check(dgf, dg64, 2e-2, "dgamma vs oracle")
+        check(dbf, db64, 2e-2, "dbeta vs oracle")

@@ -623,6 +623,172 @@ __global__ __launch_bounds__(RT) void addln_bwd_fast_kernel(const void* __restri
     write_partials<VEC, MAXI, 2>(acc, lds, partials + (size_t)blockIdx.x * 2 * n, n, lane, wave);
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-level Haar DWT along the embedding axis + LayerNorm-1 + residual as ONE row kernel each way (bf16, D = 512 KD):
+//   out = LN(haar(x)) * gamma + beta + x      (SpectreEncoderLayer with the 'dwt_embed' mixer: norm1(mix(x)) + x, spectre.py:66)
+// Lane l owns input elements [8c, 8c + 8) of chunk c = 64 j + l, i.e. four pairs, hence the band values a at 4c .. 4c + 3 and d at
+// D/2 + 4c .. -- the transform is lane-local both ways, LayerNorm's statistics do not care about the order, and the column
+// layout (i * 64 + lane) * 4 of write_partials is exactly this ownership (i = j for the averages, KD + j for the differences).
+// Nothing of the mixer is stored: the backward recomputes haar(x) from x.  Replaces haar (12 us) + add+LayerNorm (16 us) forward and
+// add+LayerNorm backward (32 us) + inverse haar (12 us) per layer.
+template <int KD>
+__global__ __launch_bounds__(RT) void haar_ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o, int rows) {
+    constexpr int D = 512 * KD, H = D / 2;
+    const float r = 0.70710678118654752440f;
+    const int lane = threadIdx.x & 63;
+    const int wave_g = blockIdx.x * RW + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * RW;
+    for (int row = wave_g; row < rows; row += nwaves) {
+        const bf16_t* xr = x + (size_t)row * D;
+        uint4 raw[KD];
+        uint2 xa[KD], xd[KD];
+#pragma unroll
+        for (int j = 0; j < KD; ++j) {
+            const int c = 64 * j + lane;
+            raw[j] = *reinterpret_cast<const uint4*>(xr + 8 * c);
+            xa[j] = *reinterpret_cast<const uint2*>(xr + 4 * c);          // the residual at the positions this lane writes
+            xd[j] = *reinterpret_cast<const uint2*>(xr + H + 4 * c);
+        }
+        float av[KD][4], dv[KD][4], s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KD; ++j) {
+            const unsigned w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x0 = __uint_as_float(w[u] << 16), x1 = __uint_as_float(w[u] & 0xffff0000u);
+                // the unfused path stores the band values as bf16 before LayerNorm reads them: keep its rounding
+                av[j][u] = bf2f(f2bf((x0 + x1) * r));
+                dv[j][u] = bf2f(f2bf((x0 - x1) * r));
+                s += av[j][u] + dv[j][u];
+            }
+        }
+        const float mu = wave_sum(s) * (1.0f / (float)D);
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KD; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float e0 = av[j][u] - mu, e1 = dv[j][u] - mu;
+                q += e0 * e0 + e1 * e1;
+            }
+        const float rs = rsqrtf(wave_sum(q) * (1.0f / (float)D) + 1e-5f);
+        if (lane == 0) { mean_o[row] = mu; rstd_o[row] = rs; }
+        bf16_t* orow = out + (size_t)row * D;
+#pragma unroll
+        for (int j = 0; j < KD; ++j) {
+            const int c = 64 * j + lane;
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c), gd = *reinterpret_cast<const float4*>(gamma + H + 4 * c);
+            const float4 ba = *reinterpret_cast<const float4*>(beta + 4 * c), bd = *reinterpret_cast<const float4*>(beta + H + 4 * c);
+            const float g0[4] = {ga.x, ga.y, ga.z, ga.w}, g1[4] = {gd.x, gd.y, gd.z, gd.w};
+            const float b0[4] = {ba.x, ba.y, ba.z, ba.w}, b1[4] = {bd.x, bd.y, bd.z, bd.w};
+            const float ra[4] = {__uint_as_float(xa[j].x << 16), __uint_as_float(xa[j].x & 0xffff0000u), __uint_as_float(xa[j].y << 16),
+                                 __uint_as_float(xa[j].y & 0xffff0000u)};
+            const float rd[4] = {__uint_as_float(xd[j].x << 16), __uint_as_float(xd[j].x & 0xffff0000u), __uint_as_float(xd[j].y << 16),
+                                 __uint_as_float(xd[j].y & 0xffff0000u)};
+            float oa[4], od[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                oa[u] = (av[j][u] - mu) * rs * g0[u] + b0[u] + ra[u];
+                od[u] = (dv[j][u] - mu) * rs * g1[u] + b1[u] + rd[u];
+            }
+            uint2 wa, wd;
+            wa.x = pack_bf16x2(oa[0], oa[1]); wa.y = pack_bf16x2(oa[2], oa[3]);
+            wd.x = pack_bf16x2(od[0], od[1]); wd.y = pack_bf16x2(od[2], od[3]);
+            *reinterpret_cast<uint2*>(orow + 4 * c) = wa;
+            *reinterpret_cast<uint2*>(orow + H + 4 * c) = wd;
+        }
+    }
+}
+
+template <int KD>
+__global__ __launch_bounds__(RT) void haar_ln_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+                                                          const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                          const float* __restrict__ gamma, bf16_t* __restrict__ dx,
+                                                          float* __restrict__ partials, int rows) {
+    constexpr int D = 512 * KD, H = D / 2, MAXI = 2 * KD;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float r = 0.70710678118654752440f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_g = blockIdx.x * RW + wave;
+    const int nwaves = gridDim.x * RW;
+    float acc[2][MAXI][4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[p][i][k] = 0.0f;
+    float g0[KD][4], g1[KD][4];
+#pragma unroll
+    for (int j = 0; j < KD; ++j) {
+        const int c = 64 * j + lane;
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c), gd = *reinterpret_cast<const float4*>(gamma + H + 4 * c);
+        g0[j][0] = ga.x; g0[j][1] = ga.y; g0[j][2] = ga.z; g0[j][3] = ga.w;
+        g1[j][0] = gd.x; g1[j][1] = gd.y; g1[j][2] = gd.z; g1[j][3] = gd.w;
+    }
+    for (int row = wave_g; row < rows; row += nwaves) {
+        const bf16_t* xr = x + (size_t)row * D;
+        const bf16_t* dr = dout + (size_t)row * D;
+        uint4 raw[KD], res[KD];
+        uint2 da[KD], dd[KD];
+#pragma unroll
+        for (int j = 0; j < KD; ++j) {
+            const int c = 64 * j + lane;
+            raw[j] = *reinterpret_cast<const uint4*>(xr + 8 * c);
+            res[j] = *reinterpret_cast<const uint4*>(dr + 8 * c);          // the residual path's gradient for the lane's 8 inputs
+            da[j] = *reinterpret_cast<const uint2*>(dr + 4 * c);           // dout at the band positions this lane owns
+            dd[j] = *reinterpret_cast<const uint2*>(dr + H + 4 * c);
+        }
+        const float mu = mean_i[row], rs = rstd_i[row];
+        float xh0[KD][4], xh1[KD][4], t0[KD][4], t1[KD][4], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KD; ++j) {
+            const unsigned w[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+            const float d0[4] = {__uint_as_float(da[j].x << 16), __uint_as_float(da[j].x & 0xffff0000u), __uint_as_float(da[j].y << 16),
+                                 __uint_as_float(da[j].y & 0xffff0000u)};
+            const float d1[4] = {__uint_as_float(dd[j].x << 16), __uint_as_float(dd[j].x & 0xffff0000u), __uint_as_float(dd[j].y << 16),
+                                 __uint_as_float(dd[j].y & 0xffff0000u)};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float x0 = __uint_as_float(w[u] << 16), x1 = __uint_as_float(w[u] & 0xffff0000u);
+                const float a = bf2f(f2bf((x0 + x1) * r)), d = bf2f(f2bf((x0 - x1) * r));
+                xh0[j][u] = (a - mu) * rs;
+                xh1[j][u] = (d - mu) * rs;
+                acc[0][j][u] += d0[u] * xh0[j][u];
+                acc[1][j][u] += d0[u];
+                acc[0][KD + j][u] += d1[u] * xh1[j][u];
+                acc[1][KD + j][u] += d1[u];
+                t0[j][u] = d0[u] * g0[j][u];
+                t1[j][u] = d1[u] * g1[j][u];
+                s1 += t0[j][u] + t1[j][u];
+                s2 += t0[j][u] * xh0[j][u] + t1[j][u] * xh1[j][u];
+            }
+        }
+        const float m1 = wave_sum(s1) * (1.0f / (float)D), m2 = wave_sum(s2) * (1.0f / (float)D);
+        bf16_t* orow = dx + (size_t)row * D;
+#pragma unroll
+        for (int j = 0; j < KD; ++j) {
+            const int c = 64 * j + lane;
+            const unsigned wr[4] = {res[j].x, res[j].y, res[j].z, res[j].w};
+            float o[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // the unfused path stores d(haar output) as bf16 before the inverse transform reads it: keep its rounding
+                const float ga = bf2f(f2bf(rs * (t0[j][u] - m1 - xh0[j][u] * m2)));
+                const float gd = bf2f(f2bf(rs * (t1[j][u] - m1 - xh1[j][u] * m2)));
+                o[2 * u] = (ga + gd) * r + __uint_as_float(wr[u] << 16);
+                o[2 * u + 1] = (ga - gd) * r + __uint_as_float(wr[u] & 0xffff0000u);
+            }
+            uint4 t;
+            t.x = pack_bf16x2(o[0], o[1]); t.y = pack_bf16x2(o[2], o[3]); t.z = pack_bf16x2(o[4], o[5]); t.w = pack_bf16x2(o[6], o[7]);
+            *reinterpret_cast<uint4*>(orow + 8 * c) = t;
+        }
+    }
+    write_partials<4, MAXI, 2>(acc, lds, partials + (size_t)blockIdx.x * 2 * D, D, lane, wave);
+}
+
 // out[p][c] = sum_w partials[w][p][c]; a workgroup of 1024 threads owns 16 columns (64-byte segments), 64 thread rows
 // split the slabs (<= 16 loads each at 1024 slabs: the kernel is latency bound, so the loads must be spread thin),
 // fixed summation order
@@ -1193,6 +1359,41 @@ extern "C" int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const 
     SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd");
     if (dgamma != nullptr) hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(5 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, lwgs, 5, n, dgamma2, dbeta2);
     SPV_LAUNCH_CHECK("spv_spectre_tail_ln_bwd(fold)");
+    return 0;
+}
+
+extern "C" int spv_haar_ln_supported(int dim, int dtype) {
+    static const bool off = getenv("SPV_HAAR_NO_FUSE") != nullptr;   // A/B switch
+    return (!off && dtype == SPV_BF16 && (dim == 512 || dim == 1024)) ? 1 : 0;
+}
+
+extern "C" int spv_haar_ln_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd, int rows, int dim,
+                               int dtype, void* stream) {
+    SPV_CHECK(rows > 0 && spv_haar_ln_supported(dim, dtype), "spv_haar_ln_fwd: unsupported dim %d / dtype %d", dim, dtype);
+    SPV_CHECK(x && gamma && beta && out && mean && rstd, "spv_haar_ln_fwd: null pointer");
+    SPV_CHECK((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "spv_haar_ln_fwd: pointers must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(std::min(cdiv(rows, RW), 2048));
+    if (dim == 512) hipLaunchKernelGGL((haar_ln_fwd_kernel<1>), grid, dim3(RT), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)out, mean, rstd, rows);
+    else hipLaunchKernelGGL((haar_ln_fwd_kernel<2>), grid, dim3(RT), 0, st, (const bf16_t*)x, gamma, beta, (bf16_t*)out, mean, rstd, rows);
+    SPV_LAUNCH_CHECK("spv_haar_ln_fwd");
+    return 0;
+}
+
+// dgamma == NULL: the caller folds the partials (parts = spv_tail_bwd_parts(rows), nsum = 2, n = dim); partials: spv_rowop_partial_floats(dim)
+extern "C" int spv_haar_ln_bwd(const void* dout, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                               float* dgamma, float* dbeta, float* partials, int rows, int dim, int dtype, void* stream) {
+    SPV_CHECK(rows > 0 && spv_haar_ln_supported(dim, dtype), "spv_haar_ln_bwd: unsupported dim %d / dtype %d", dim, dtype);
+    SPV_CHECK(dout && x && mean && rstd && gamma && dx && partials && ((dgamma != nullptr) == (dbeta != nullptr)), "spv_haar_ln_bwd: null pointer");
+    SPV_CHECK((((uintptr_t)x | (uintptr_t)dout | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0, "spv_haar_ln_bwd: pointers must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int wgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
+    const size_t lds = (size_t)2 * dim * sizeof(float);
+    if (dim == 512) hipLaunchKernelGGL((haar_ln_bwd_kernel<1>), dim3(wgs), dim3(RT), lds, st, (const bf16_t*)dout, (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, partials, rows);
+    else hipLaunchKernelGGL((haar_ln_bwd_kernel<2>), dim3(wgs), dim3(RT), lds, st, (const bf16_t*)dout, (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, partials, rows);
+    SPV_LAUNCH_CHECK("spv_haar_ln_bwd");
+    if (dgamma != nullptr) hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(2 * dim, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, (float*)nullptr, wgs, 2, dim);
+    SPV_LAUNCH_CHECK("spv_haar_ln_bwd(fold)");
     return 0;
 }
 

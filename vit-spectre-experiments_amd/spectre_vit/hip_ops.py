@@ -255,6 +255,8 @@ _WORK_MODELS = {
     "spv_fnet_ln_fwd": lambda i: ("fnet_ln_fwd", i[0:3], i[3], "hbm", 3.0 * i[0] * i[1] * i[2] * _es(i[3])),
     # read dout and the pre-norm tensor, write dx
     "spv_fnet_ln_bwd": lambda i: ("fnet_ln_bwd", i[0:3], i[3], "hbm", 3.0 * i[0] * i[1] * i[2] * _es(i[3])),
+    "spv_haar_ln_fwd": lambda i: ("haar_ln_fwd", i[0:2], i[2], "hbm", 2.0 * i[0] * i[1] * _es(i[2])),
+    "spv_haar_ln_bwd": lambda i: ("haar_ln_bwd", i[0:2], i[2], "hbm", 3.0 * i[0] * i[1] * _es(i[2])),
     "spv_haar_dwt": lambda i: ("haar_dwt", i[0:3], i[6], "hbm", 2.0 * i[0] * i[1] * i[2] * _es(i[6])),
     # p, g, m, v read + p, m, v written, 2048 elements per workgroup (the last chunk of a tensor is short: an upper bound)
     "spv_adamw_multi": lambda i: ("adamw_multi", i[0:1], F32, "hbm", 7.0 * 4 * 2048 * i[0]),
@@ -1400,6 +1402,48 @@ class FNetResidualFn(torch.autograd.Function):
         dm, dn1w, dn1b = _addln_backward(d2, sn)
         dx = _fnet_raw(dm.reshape(B, N, D), add_in=d2)  # symmetric operator; + the residual gradient, folded in
         return dx, dn1w, dn1b
+
+
+class HaarResidualFn(torch.autograd.Function):
+    """x1 = LayerNorm1(haar(x)) + x, one-level Haar DWT along the embedding axis (reference spectre.py:66 with the 'dwt_embed' mixer of
+    BASELINE config 3): one row kernel each way (spv_haar_ln_fwd / _bwd; the transform is lane-local, nothing of the mixer is stored)."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b):
+        _require_gpu(x)
+        xc = x.contiguous()
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        dev = xc.device
+        out = torch.empty_like(xc)
+        mean = torch.empty((rows,), dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        _native.call("spv_haar_ln_fwd", _p(xc), _p(n1w), _p(n1b), _p(out), _p(mean), _p(rstd), rows, D, _dt(xc), _stream())
+        ctx.save_for_backward(xc, mean, rstd, n1w)
+        ctx.sinks = (_sink(n1w), _sink(n1b))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xc, mean, rstd, n1w = ctx.saved_tensors
+        D = xc.shape[-1]
+        rows = xc.numel() // D
+        dev = xc.device
+        d2 = dout.contiguous()
+        dx = torch.empty_like(xc)
+        dn1w = _grad_buf(ctx.sinks[0], (D,), dev)
+        dn1b = _grad_buf(ctx.sinks[1], (D,), dev)
+        partials = torch.empty((_native.call("spv_rowop_partial_floats", D),), dtype=torch.float32, device=dev)
+        # the fold of the column sums travels with the next weight-gradient reduce of the backward pass (sink memory only: _hold_fold)
+        held = _hold_fold(partials, (dn1w, dn1b), ctx.sinks, _native.call("spv_tail_bwd_parts", rows), D)
+        _native.call("spv_haar_ln_bwd", _p(d2), _p(xc), _p(mean), _p(rstd), _p(n1w), _p(dx), 0 if held else _p(dn1w), 0 if held else _p(dn1b),
+                     _p(partials), rows, D, _dt(xc), _stream())
+        return dx, dn1w, dn1b
+
+
+def haar_ln_ok(x, axis, levels):
+    return bool(axis == "embed" and levels == 1 and x.is_cuda and x.dtype == torch.bfloat16
+                and _native.call("spv_haar_ln_supported", x.shape[-1], _dt(x)))
 
 
 class PermutMixFn(torch.autograd.Function):

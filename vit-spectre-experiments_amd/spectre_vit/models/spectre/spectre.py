@@ -68,6 +68,8 @@ class SpectreEncoderLayer(nn.Module):
         x = hip_ops.cast(x, hip_ops.compute_dtype(x))
         if self.mixer == "fft":  # mixer + norm1 + residual as one autograd node (residual gradient folded into the FFT kernel)
             x = hip_ops.FNetResidualFn.apply(x, self.norm1.weight, self.norm1.bias)
+        elif self.mixer == "dwt_embed" and hip_ops.haar_ln_ok(x, self.mix_layer.axis, self.mix_layer.levels):
+            x = hip_ops.HaarResidualFn.apply(x, self.norm1.weight, self.norm1.bias)   # mixer + norm1 + residual as one row kernel each way
         else:
             x = hip_ops.add_layernorm(self.mix_layer(x), x, self.norm1.weight, self.norm1.bias, 0)
         l1, l3 = self.linear1.local_head, self.linear3.local_head
