@@ -1311,9 +1311,10 @@ __global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void splitk_reduce_fold_kern
     const int fold_blocks = fj.first_block[fj.njobs];
     if ((int)blockIdx.x < fold_blocks)
         fold_jobs_block(fj, (int)blockIdx.x, threadIdx.x);
-    else
-        splitk_reduce_body<TO>(ws, nullptr, C, M, N, ldc, splits, accumulate, blockIdx.x - fold_blocks, reduce_blocks, threadIdx.x,
-                               FOLD_COLS * FOLD_ROWS);
+    else if (threadIdx.x < 256)
+        // a quarter of the block's threads each: the sum has 98 k four-column quads at the layer shapes -- as 1024-thread blocks that is
+        // 96 workgroups for 256 CUs; as 256 live threads per block, 384
+        splitk_reduce_body<TO>(ws, nullptr, C, M, N, ldc, splits, accumulate, blockIdx.x - fold_blocks, reduce_blocks, threadIdx.x, 256);
 }
 
 inline int kend_len(int K, int k_per_split) { return K < k_per_split ? K : k_per_split; }
@@ -1574,7 +1575,7 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
     if (splits > 1) {
         if (fold_blocks > 0) {
             constexpr int RT1 = FOLD_COLS * FOLD_ROWS;
-            const int blocks = (int)std::min<int64_t>(((int64_t)M * N / ((N & 3) == 0 ? 4 : 1) + RT1 - 1) / RT1, 2048);
+            const int blocks = (int)std::min<int64_t>(((int64_t)M * N / ((N & 3) == 0 ? 4 : 1) + 255) / 256, 2048);
             if (out_dtype == SPV_BF16)
                 hipLaunchKernelGGL((splitk_reduce_fold_kernel<bf16_t>), dim3(blocks + fold_blocks), dim3(RT1), 0, st, ws, (bf16_t*)C, M, N, ldc, splits,
                                    accumulate, blocks, fj);
