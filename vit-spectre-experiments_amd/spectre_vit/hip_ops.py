@@ -395,6 +395,7 @@ def join_side_stream():
 # With data parallelism the bucket hooks need every gradient as soon as its node has run: nothing is held.
 # ------------------------------------------------------------------------------------------------
 _held_folds = []   # (partials, outputs, parts, n)
+_held_task = -2    # the autograd graph task (backward pass) the held folds belong to
 FOLD_RIDERS = 6    # fold jobs one reduce launch carries (csrc/spv_gemm.hip FJ_MAX)
 
 
@@ -417,23 +418,28 @@ def _fold_array(folds):
 
 def flush_held_folds():
     """run the folds still held (called by the autograd engine when the backward pass is over)"""
+    global _held_task
     if _held_folds:
         arr = _fold_array(_held_folds)
         _native.call("spv_fold_multi", ctypes.addressof(arr), len(_held_folds), _stream())
         _held_folds.clear()
+    _held_task = -2
 
 
 def _hold_fold(partials, outs, sinks, parts, n):
     """hold a fold for the next weight-gradient reduce of this backward pass.  Only when every output IS its parameter's sink slot
     (memory that outlives the node; autograd adopts the alias without copying), and never by keeping the output tensors themselves:
     a second reference makes AccumulateGrad clone the -- still unfolded -- gradient.  False (not held) otherwise."""
+    global _held_task
     if not _hold_ok() or any(sk is None or o.data_ptr() != sk.view.data_ptr() for o, sk in zip(outs, sinks)):
         return False
-    if not _held_folds:
-        try:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_held_folds)
-        except RuntimeError:   # not inside a backward pass
-            return False
+    task = torch._C._current_graph_task_id()
+    if task < 0:   # not inside a backward pass
+        return False
+    if _held_task != task:
+        _held_folds.clear()   # leftovers of a backward pass that never finished (an exception): their launch must not ride along
+        torch.autograd.Variable._execution_engine.queue_callback(flush_held_folds)
+        _held_task = task
     _held_folds.append((partials, tuple(o.data_ptr() for o in outs), parts, n))
     return True
 
@@ -472,7 +478,7 @@ def _weight_grad(dh, x, rows, n, k, sink=None, fold=None):
             if ws is None and splits > 1:
                 ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev)
             folds = [fold] if fold is not None else []
-            if riders:
+            if riders and _held_task == torch._C._current_graph_task_id():
                 while _held_folds and len(folds) < FOLD_RIDERS:
                     folds.append(_held_folds.pop(0))
             if folds:
