@@ -112,6 +112,17 @@ def test_fft_step_at_bench_shapes(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dwt_step_at_bench_shapes(dtype):
+    """BASELINE config 3 at its own size: Small / Haar-DWT (embed axis) mixer / 4 layers / bs 512, every gradient vs the float64 oracle.
+    bf16 takes the fused mixer + LayerNorm-1 + residual row kernels (spv_haar_ln_fwd / _bwd), fp32 the stand-alone Haar kernel +
+    add+LayerNorm.  (The DWT rows stay parity-UNPINNED against the reference -- it has no DWT model code, SURVEY 8a-7 -- the oracle
+    is the mathematical definition.)"""
+    m, img, labels, sd = _setup(SMALL, "dwt_embed", 512, 13)
+    ref = oracle_step("dwt512", img, labels, sd, 4, 4, "dwt_embed")
+    run_and_compare(m, img, labels, ref, dtype, "dwt_embed bs512")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_permut_layer_at_bench_shapes(dtype):
     """one encoder layer with the HEAD mixer (MHPermutMix: gather + 8192 -> 512 SpectreLinear) at bs 128."""
     cfg = dict(SMALL, num_encoders=1)
