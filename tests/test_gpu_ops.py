@@ -196,7 +196,8 @@ def sl_oracle(x, W, b, g, be, dy):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,lead", [(64, 64, (3, 7)), (256, 16, (2, 9)), (96, 64, (5, 3)), (64, 96, (4, 5)),
                                            (512, 768, (2, 65)), (768, 512, (2, 65)), (512, 104, (33,)), (1024, 64, (130,)),
-                                           (48, 256, (3, 50)), (64, 256, (9,)), (768, 3072, (5,)), (3072, 768, (5,))])
+                                           (48, 256, (3, 50)), (64, 256, (9,)), (768, 3072, (5,)), (3072, 768, (5,)),
+                                           (768, 3072, (3, 197)), (3072, 768, (3, 197))])   # Base widths: 4-waves-per-row / 48-inputs-per-lane tails
 def test_spectre_linear(ops, dtype, cin, cout, lead):
     rng = np.random.default_rng(cin * 7 + cout)
     x = q(rng.standard_normal(lead + (cin,)), dtype)
@@ -843,3 +844,32 @@ def test_haar_ln_residual_fused_vs_unfused_and_oracle(ops, B, N, D):
         check(dxf, O.haar_dwt_bwd(dm, axis=-1, levels=1) + n64(dy), 3e-2, "dx vs oracle")
         check(dgf, dg64, 2e-2, "dgamma vs oracle")
         check(dbf, db64, 2e-2, "dbeta vs oracle")
+
+
+@pytest.mark.parametrize("cin,cout", [(768, 3072), (3072, 768)])
+def test_spectre_linear_dropout_base_widths(ops, cin, cout):
+    """The Base-width tail kernels (four waves per 3072-wide row; 48 inputs per lane for 3072 -> 768) with dropout on: the forward's mask
+    (read off the zeros) must be the one the backward re-derives -- checked against torch autograd on the same composite with that mask."""
+    torch.manual_seed(1)
+    rows, p = 300, 0.25
+    X = torch.randn(rows, cin, device=dev())
+    W = torch.randn(cout, cin, device=dev()) / cin ** 0.5
+    b, g, be = torch.randn(cout, device=dev()) * 0.1, torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev()) * 0.1
+    dy = torch.randn(rows, cout, device=dev())
+    Xg = X.clone().requires_grad_(True)
+    ps = [t_.clone().requires_grad_(True) for t_ in (W, b, g, be)]
+    y = ops.spectre_linear(Xg, *ps, p, False)
+    y.backward(dy)
+    kept = (y != 0)
+    assert abs(kept.float().mean().item() - (1 - p)) < 0.01
+    Xr = X.clone().requires_grad_(True)
+    pr = [t_.clone().requires_grad_(True) for t_ in (W, b, g, be)]
+    h = torch.nn.functional.linear(Xr, pr[0], pr[1])
+    f = torch.nn.functional.gelu(torch.nn.functional.layer_norm(h, (cout,), pr[2], pr[3]))
+    f = f + torch.nn.functional.adaptive_avg_pool1d(Xr.unsqueeze(1), cout).squeeze(1)
+    ref = f * kept / (1 - p)
+    ref.backward(dy)
+    check(y, n64(ref), 3e-5, "y")
+    check(Xg.grad, n64(Xr.grad), 1e-4, "dx")
+    for a_, r_, name in zip(ps, pr, ("dW", "db", "dgamma", "dbeta")):
+        check(a_.grad, n64(r_.grad), 1e-4, name)

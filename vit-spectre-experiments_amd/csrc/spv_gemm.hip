@@ -792,7 +792,7 @@ static int g_reserved_cus = 0;
 
 inline bool strip_plan(int M, int N, int K, int& MB, int& nstrips, int& groups, int& base, int& rem) {
     static const int enabled = getenv("SPV_GEMM_STRIP") ? atoi(getenv("SPV_GEMM_STRIP")) : 1;
-    if (!enabled || N % 256 != 0 || N > 8192 || K % 128 != 0 || K < 128 || M < 8192) return false;
+    if (!enabled || N % 256 != 0 || N > 16384 || K % 128 != 0 || K < 128 || M < 8192) return false;   // (Base width: the MHPermutMix data gradient has N = 9216)
     nstrips = N / 256;
     const int nblk = cdiv(M, 32);
     groups = (256 - g_reserved_cus) / nstrips;

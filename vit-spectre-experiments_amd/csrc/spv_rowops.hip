@@ -1005,8 +1005,11 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
             ld_raw<CO, bf>(ln.f3, (size_t)row * n + lane * CO, r_s);
             ld_raw<CO, bf>(ln.res, (size_t)row * n + lane * CO, r_t);
         }
-        if (!LN2 && up.src != nullptr) ld_raw<CI, bf>(up.src, (size_t)row * k_in + lane * CI, r_u);
-        if (dxp != nullptr && dx_add != nullptr) ld_raw<CI, bf>(dx_add, (size_t)row * k_in + lane * CI, r_a);
+        constexpr bool WIDE_IN = CI > 16;   // many inputs per lane (3072 -> 768 at the Base width): the skip gradient goes out in chunks
+        if constexpr (!WIDE_IN) {
+            if (!LN2 && up.src != nullptr) ld_raw<CI, bf>(up.src, (size_t)row * k_in + lane * CI, r_u);
+            if (dxp != nullptr && dx_add != nullptr) ld_raw<CI, bf>(dx_add, (size_t)row * k_in + lane * CI, r_a);
+        }
         const float mean = mean_i[row], rstd = rstd_i[row];
         const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed_l, (uint64_t)row) : 0u;
         const unsigned lane_gold = (unsigned)(lane * (CO / 2)) * 0x9e3779b1u;  // this lane's first column pair in the mask hash
@@ -1125,6 +1128,32 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
         st_span<CO>(dh, (size_t)row * n + lane * CO, bf, o);
         if (dxp == nullptr) continue;  // the consumer takes the skip gradient from this layer's incoming gradient (TailUp)
         // transposed pooling, lane local: input j receives dout[c] / width(c) from every window that covers it
+        if constexpr (WIDE_IN) {
+            // eight inputs at a time, stored as they are formed (a 48-element array and its residual's raw copy spilled 130 VGPRs)
+#pragma unroll
+            for (int j0 = 0; j0 < CI; j0 += 8) {
+                float dxc[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j = j0 + jj;
+                    float a = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < CO; ++c)
+                        if (j >= lc_ws(c, CO, CI) && j < lc_we(c, CO, CI)) a += dv[c] * (1.0f / (float)(lc_we(c, CO, CI) - lc_ws(c, CO, CI)));
+                    dxc[jj] = a;
+                }
+                if (dx_add != nullptr) {
+                    RawSpan<8, bf> ra;
+                    ld_raw<8, bf>(dx_add, (size_t)row * k_in + lane * CI + j0, ra);
+                    float ad[8];
+                    unpack<8, bf>(ra, ad);
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) dxc[jj] += ad[jj];
+                }
+                st_span<8>(dxp, (size_t)row * k_in + lane * CI + j0, bf, dxc);
+            }
+            continue;
+        }
         float dx[CI];
 #pragma unroll
         for (int j = 0; j < CI; ++j) {
@@ -1154,6 +1183,158 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
         for (int w = 1; w < RW; ++w) v += lds[w * NP * n + off];
         slab[i] = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// SpectreLinear tail for WIDE rows whose skip repeats every input WR = 4 times (768 -> 3072: linear1 at the Base width): the four waves
+// of a workgroup share ONE row -- wave w owns columns [768 w, 768 w + 768) = 12 outputs and 3 inputs per lane, windows lane-local --
+// and join their LayerNorm sums through LDS.  (The generic kernel holds 48 fp32 outputs per lane, branches per 2-byte skip load and
+// divides per element: 543 us forward / 541 us backward per Base layer at bs 64, 15x its bytes' worth.)  Column sums need no LDS: a
+// wave sees the same columns in every row, so they live in 36 registers per lane until the slab is written.
+constexpr int WCO = 12, WR = 4, WCI = WCO / WR;
+template <int BF, bool FASTG>
+__global__ __launch_bounds__(RT) void tail_wide_fwd_kernel(const void* __restrict__ h, const void* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, void* __restrict__ out, float* __restrict__ mean_o,
+                                                           float* __restrict__ rstd_o, int rows, float p_drop, uint64_t seed) {
+    constexpr int n = RW * 64 * WCO, k_in = n / WR;
+    __shared__ float red[2][2][RW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col0 = (wave * 64 + lane) * WCO, in0 = (wave * 64 + lane) * WCI;
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint64_t seed_l = live_seed(seed);
+    float g[WCO], b[WCO];
+    ld_span<WCO>(gamma, col0, 0, g);
+    ld_span<WCO>(beta, col0, 0, b);
+    int par = 0;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
+        RawSpan<WCO, BF> r_h;
+        ld_raw<WCO, BF>(h, (size_t)row * n + col0, r_h);
+        float xv[WCI];
+#pragma unroll
+        for (int j = 0; j < WCI; ++j) xv[j] = BF ? bf2f(static_cast<const bf16_t*>(x)[(size_t)row * k_in + in0 + j]) : static_cast<const float*>(x)[(size_t)row * k_in + in0 + j];
+        float hv[WCO];
+        unpack<WCO, BF>(r_h, hv);
+        float sm = 0.0f;
+#pragma unroll
+        for (int c = 0; c < WCO; ++c) sm += hv[c];
+        sm = wave_sum(sm);
+        if (lane == 0) red[par][0][wave] = sm;
+        __syncthreads();
+        float tot = 0.0f;
+#pragma unroll
+        for (int w = 0; w < RW; ++w) tot += red[par][0][w];
+        const float mean = tot / (float)n;
+        float q = 0.0f;
+#pragma unroll
+        for (int c = 0; c < WCO; ++c) { const float d = hv[c] - mean; q += d * d; }
+        q = wave_sum(q);
+        if (lane == 0) red[par][1][wave] = q;
+        __syncthreads();
+        float qt = 0.0f;
+#pragma unroll
+        for (int w = 0; w < RW; ++w) qt += red[par][1][w];
+        const float rstd = rsqrtf(qt / (float)n + LN_EPS);
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed_l, (uint64_t)row) : 0u;
+        float o[WCO];
+#pragma unroll
+        for (int c = 0; c < WCO; ++c) {
+            const float ln = (hv[c] - mean) * rstd * g[c] + b[c];
+            float act, unused;
+            if (FASTG) gelu_fast(ln, act, unused);
+            else act = gelu_erf(ln);
+            o[c] = act + xv[c / WR];
+            if (p_drop > 0.0f) o[c] *= dropout_scale(rkey, (unsigned)(col0 + c), p_drop, inv_keep);
+        }
+        st_span<WCO>(out, (size_t)row * n + col0, BF, o);
+        if (threadIdx.x == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+    }
+}
+
+template <int BF, bool FASTG>
+__global__ __launch_bounds__(RT) void tail_wide_bwd_kernel(const void* __restrict__ dout, const void* __restrict__ h, const float* __restrict__ mean_i,
+                                                           const float* __restrict__ rstd_i, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, void* __restrict__ dh, void* __restrict__ dxp,
+                                                           float* __restrict__ partials, int rows, float p_drop, uint64_t seed,
+                                                           const void* __restrict__ dx_add) {
+    constexpr int n = RW * 64 * WCO, k_in = n / WR;
+    __shared__ float red[2][2][RW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col0 = (wave * 64 + lane) * WCO, in0 = (wave * 64 + lane) * WCI;
+    const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint64_t seed_l = live_seed(seed);
+    float g[WCO], b[WCO], acc[3][WCO];
+    ld_span<WCO>(gamma, col0, 0, g);
+    ld_span<WCO>(beta, col0, 0, b);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int c = 0; c < WCO; ++c) acc[p][c] = 0.0f;
+    int par = 0;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
+        RawSpan<WCO, BF> r_h, r_d;
+        ld_raw<WCO, BF>(dout, (size_t)row * n + col0, r_d);
+        ld_raw<WCO, BF>(h, (size_t)row * n + col0, r_h);
+        float ad[WCI];
+#pragma unroll
+        for (int j = 0; j < WCI; ++j) ad[j] = 0.0f;
+        if (dxp != nullptr && dx_add != nullptr) {
+#pragma unroll
+            for (int j = 0; j < WCI; ++j)
+                ad[j] = BF ? bf2f(static_cast<const bf16_t*>(dx_add)[(size_t)row * k_in + in0 + j]) : static_cast<const float*>(dx_add)[(size_t)row * k_in + in0 + j];
+        }
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed_l, (uint64_t)row) : 0u;
+        float hv[WCO], dv[WCO], xh[WCO], t[WCO];
+        unpack<WCO, BF>(r_h, hv);
+        unpack<WCO, BF>(r_d, dv);
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < WCO; ++c) {
+            if (p_drop > 0.0f) dv[c] *= dropout_scale(rkey, (unsigned)(col0 + c), p_drop, inv_keep);
+            xh[c] = (hv[c] - mean) * rstd;
+            float dgel, unused;
+            if (FASTG) gelu_fast(xh[c] * g[c] + b[c], unused, dgel);
+            else dgel = gelu_erf_grad(xh[c] * g[c] + b[c]);
+            const float dln = dv[c] * dgel;
+            acc[0][c] += dln * xh[c];
+            acc[1][c] += dln;
+            t[c] = dln * g[c];
+            s1 += t[c];
+            s2 += t[c] * xh[c];
+        }
+        s1 = wave_sum(s1);
+        s2 = wave_sum(s2);
+        if (lane == 0) { red[par][0][wave] = s1; red[par][1][wave] = s2; }
+        __syncthreads();
+        float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < RW; ++w) { m1 += red[par][0][w]; m2 += red[par][1][w]; }
+        m1 /= (float)n;
+        m2 /= (float)n;
+        float o[WCO];
+#pragma unroll
+        for (int c = 0; c < WCO; ++c) {
+            o[c] = rstd * (t[c] - m1 - xh[c] * m2);
+            acc[2][c] += o[c];
+        }
+        st_span<WCO>(dh, (size_t)row * n + col0, BF, o);
+        if (dxp != nullptr) {   // transposed repeat: an input collects the (masked) gradients of its WR outputs
+#pragma unroll
+            for (int j = 0; j < WCI; ++j) {
+                float a = ad[j];
+#pragma unroll
+                for (int r = 0; r < WR; ++r) a += dv[j * WR + r];
+                if (BF) static_cast<bf16_t*>(dxp)[(size_t)row * k_in + in0 + j] = f2bf(a);
+                else static_cast<float*>(dxp)[(size_t)row * k_in + in0 + j] = a;
+            }
+        }
+    }
+    float* slab = partials + (size_t)blockIdx.x * 3 * n;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int c = 0; c < WCO; c += 4)
+            *reinterpret_cast<float4*>(slab + (size_t)p * n + col0 + c) = make_float4(acc[p][c], acc[p][c + 1], acc[p][c + 2], acc[p][c + 3]);
 }
 
 #define TAIL_DISPATCH(cfg, fast, KERNEL, grid, lds_bytes, st, ...)                                              \
@@ -1233,7 +1414,17 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
         LC_FWD(12, 8)
         LC_FWD(8, 12)
         LC_FWD(8, 8)   // 512 -> 512, identity skip: the MHPermutMix linear with its skip pooled by the gather
+        LC_FWD(12, 48) // 3072 -> 768: linear3 at the Base width (exact windows of 4)
 #undef LC_FWD
+    }
+    static const bool no_wide = getenv("SPV_TAIL_NO_WIDE") != nullptr;   // A/B switch
+    if (!no_wide && n == RW * 64 * WCO && k_in * WR == n && (out_dtype == SPV_BF16) == (dtype == SPV_BF16) &&
+        (((uintptr_t)h | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) {
+        const dim3 wgrid(std::min(rows, 2048));
+        if (dtype == SPV_BF16) hipLaunchKernelGGL((tail_wide_fwd_kernel<1, true>), wgrid, dim3(RT), 0, st, h, x, gamma, beta, out, mean, rstd, rows, p_drop, seed);
+        else hipLaunchKernelGGL((tail_wide_fwd_kernel<0, false>), wgrid, dim3(RT), 0, st, h, x, gamma, beta, out, mean, rstd, rows, p_drop, seed);
+        SPV_LAUNCH_CHECK("spv_spectre_tail_fwd(wide)");
+        return 0;
     }
     const int pm = pool_mode_of(n, k_in);
     dim3 grid(std::min(cdiv(rows, RW), 2048));
@@ -1276,7 +1467,22 @@ static int tail_bwd_impl(const void* dout, const void* h, const float* mean, con
         LC_BWD(12, 8)
         LC_BWD(8, 12)
         LC_BWD(8, 8)
+        LC_BWD(12, 48)
 #undef LC_BWD
+    }
+    static const bool no_wide = getenv("SPV_TAIL_NO_WIDE") != nullptr;   // A/B switch
+    if (!no_wide && up.src == nullptr && n == RW * 64 * WCO && k_in * WR == n && (dout_dtype == SPV_BF16) == (dtype == SPV_BF16) &&
+        (((uintptr_t)h | (uintptr_t)dout | (uintptr_t)dh | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)partials) & 15) == 0) {
+        // one workgroup per row at a time; the slab count is the same function of rows as everywhere (spv_tail_bwd_parts)
+        const int wwgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
+        if (dtype == SPV_BF16)
+            hipLaunchKernelGGL((tail_wide_bwd_kernel<1, true>), dim3(wwgs), dim3(RT), 0, st, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, p_drop, seed, dx_add);
+        else
+            hipLaunchKernelGGL((tail_wide_bwd_kernel<0, false>), dim3(wwgs), dim3(RT), 0, st, dout, h, mean, rstd, gamma, beta, dh, dx_pool, partials, rows, p_drop, seed, dx_add);
+        SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(wide)");
+        if (dgamma != nullptr) hipLaunchKernelGGL(fold_partials_kernel, dim3(cdiv(3 * n, FOLD_COLS)), dim3(FOLD_COLS * FOLD_ROWS), 0, st, partials, dgamma, dbeta, dbias, wwgs, 3, n);
+        SPV_LAUNCH_CHECK("spv_spectre_tail_bwd(wide fold)");
+        return 0;
     }
     const int pm = pool_mode_of(n, k_in);
     const int wgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
