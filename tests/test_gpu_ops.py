@@ -873,3 +873,21 @@ def test_spectre_linear_dropout_base_widths(ops, cin, cout):
     check(Xg.grad, n64(Xr.grad), 1e-4, "dx")
     for a_, r_, name in zip(ps, pr, ("dW", "db", "dgamma", "dbeta")):
         check(a_.grad, n64(r_.grad), 1e-4, name)
+
+
+@pytest.mark.parametrize("M,N,K,pw", [(8320, 1024, 128, 16), (8320, 768, 128, 12), (8352, 1536, 256, 24), (300, 96, 64, 12)])
+def test_gemm_pool_bwd_windows(ops, M, N, K, pw):
+    """spv_gemm_nt_pool_bwd: C = A B^T + dout[:, col / pw] / pw (the transposed exact-window pooling of the MHPermutMix linear's skip,
+    layers.py:66,93) -- on the strip kernel for M >= 8192 (windows of any width >= 8: a lane's 8 columns span at most two), on the
+    128 x 128 kernel otherwise; vs float64."""
+    from spectre_vit import _native
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M + pw)
+    A = torch.randn(M, K, generator=g).to(dev()).to(bf)
+    B = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev()).to(bf)
+    D = torch.randn(M, N // pw, generator=g).to(dev()).to(bf)
+    C = torch.empty(M, N, device=dev(), dtype=bf)
+    _native.call("spv_gemm_nt_pool_bwd", A.data_ptr(), B.data_ptr(), C.data_ptr(), D.data_ptr(), pw, M, N, K, K, K, N, 1, 1, 1,
+                 torch.cuda.current_stream().cuda_stream)
+    ref = n64(A) @ n64(B).T + np.repeat(n64(D), pw, axis=1) / pw
+    check(C, ref, 1.5e-2, f"pool_bwd pw={pw}")
