@@ -470,7 +470,8 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
                                                             int lda, int ldb, int ldc, int nstrips, int base, int rem, int nwg,
                                                             const bf16_t* __restrict__ bc, int bc_pw, int bc_ld) {
     constexpr bool ACC = EPIM == 1;
-    constexpr bool BCM = EPIM == 2;
+    constexpr bool BCM = EPIM == 2 || EPIM == 3;
+    constexpr bool BC2 = EPIM == 3;   // pooling windows that are not multiples of 8 wide (Base: 12): a lane's 8 columns span two windows
     const float bc_scale = BCM ? 1.0f / (float)bc_pw : 0.0f;
     constexpr int TM = 64 * MB;                       // rows of a sub-tile without the extra block
     constexpr int STAGE = (TM + 32 + 256) * 128;      // one K-tile: A rows, extra A rows, B rows, 128 B (64 bf16) each
@@ -605,12 +606,22 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
                 for (int it = 0; it < 2; ++it) {  // one pooled value per lane and store: its 8 columns lie in one window (bc_pw % 8 == 0)
                     const int q = lane + 64 * it, lr = q >> 3, c8 = q & 7;
                     const int row = min(e_m0 + wm * 32 * MB + hb * 16 + lr, M - 1);
-                    oldv[hb][it].x = bc[(size_t)row * bc_ld + (n0 + wn * 64 + c8 * 8) / bc_pw];
+                    const int cb = n0 + wn * 64 + c8 * 8;
+                    oldv[hb][it].x = bc[(size_t)row * bc_ld + cb / bc_pw];
+                    if constexpr (BC2) {
+                        oldv[hb][it].y = bc[(size_t)row * bc_ld + (cb + 7) / bc_pw];
+                        oldv[hb][it].z = (unsigned)((cb / bc_pw + 1) * bc_pw - cb);   // columns of the 8 that belong to the first window
+                    }
                 }
             } else if constexpr (BCM && hb < 2 * MB + 2) {
                 if (extra) {
                     const int row = min(e_m0 + TM + 16 * (hb - 2 * MB) + (lane >> 2), M - 1);
-                    oldx[hb - 2 * MB].x = bc[(size_t)row * bc_ld + (n0 + wave * 32 + (lane & 3) * 8) / bc_pw];
+                    const int cb = n0 + wave * 32 + (lane & 3) * 8;
+                    oldx[hb - 2 * MB].x = bc[(size_t)row * bc_ld + cb / bc_pw];
+                    if constexpr (BC2) {
+                        oldx[hb - 2 * MB].y = bc[(size_t)row * bc_ld + (cb + 7) / bc_pw];
+                        oldx[hb - 2 * MB].z = (unsigned)((cb / bc_pw + 1) * bc_pw - cb);
+                    }
                 }
             }
         };
@@ -695,7 +706,12 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
                 float w[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) w[u] = v[u] + bb[u];
-                if constexpr (BCM) {
+                if constexpr (BC2) {
+                    const float t0 = __uint_as_float(old.x << 16) * bc_scale, t1 = __uint_as_float(old.y << 16) * bc_scale;
+                    const int first = (int)old.z;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) w[u] += u < first ? t0 : t1;
+                } else if constexpr (BCM) {
                     const float t = __uint_as_float(old.x << 16) * bc_scale;
 #pragma unroll
                     for (int u = 0; u < 8; ++u) w[u] += t;
@@ -1338,7 +1354,7 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
     dim3 grid(tiles_m * tiles_n * splits);
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
         int mb, nstrips, groups, base, rem;
-        const bool bc_ok = bc == nullptr || (bc_bf && !accumulate && bc_pw % 8 == 0 && N % bc_pw == 0);
+        const bool bc_ok = bc == nullptr || (bc_bf && !accumulate && bc_pw >= 8 && N % bc_pw == 0);   // (8 columns span <= 2 windows)
         const bool span32 = (size_t)M * lda * 2 < (1ull << 32) && (size_t)N * ldb * 2 < (1ull << 32);  // 32-bit DMA source offsets
         if (splits == 1 && rg == 0 && bias2d == nullptr && t_drop_p == 0.0f && bc_ok && span32 && ldc % 8 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
             (bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 3) == 0) && strip_plan(M, N, K, mb, nstrips, groups, base, rem)) {
@@ -1354,7 +1370,11 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
             if (lda0) lda = 0;
             if (accumulate && acc_mb >= 2 && acc_mb <= 4) mb = acc_mb;
             SPV_COUNT_PATH(accumulate ? SPV_PATH_GEMM_STRIP_ACC : SPV_PATH_GEMM_STRIP);
-            if (bc != nullptr) {
+            if (bc != nullptr && bc_pw % 8 != 0) {   // two-window epilogue: its own instantiation (in the one-window kernel it cost 6 %)
+                if (mb == 4) SPV_STRIP(4, 3);
+                else if (mb == 3) SPV_STRIP(3, 3);
+                else SPV_STRIP(2, 3);
+            } else if (bc != nullptr) {
                 if (mb == 4) SPV_STRIP(4, 2);
                 else if (mb == 3) SPV_STRIP(3, 2);
                 else SPV_STRIP(2, 2);
