@@ -887,6 +887,7 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
     constexpr int bf = FASTG ? 1 : 0, out_bf = bf;
     (void)bf_rt; (void)out_bf_rt;
     constexpr int n = 64 * CO, k_in = 64 * CI;
+    constexpr float inv_n = 1.0f / (float)n;   // a multiply: the division by 768 (not a power of two) was ten instructions, four times per row
     const int lane = threadIdx.x & 63;
     const int wave_g = blockIdx.x * RW + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * RW;
@@ -907,11 +908,11 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
         float s = 0.0f;
 #pragma unroll
         for (int c = 0; c < CO; ++c) s += hv[c];
-        const float mean = wave_sum(s) / (float)n;
+        const float mean = wave_sum(s) * inv_n;
         float q = 0.0f;
 #pragma unroll
         for (int c = 0; c < CO; ++c) { const float d = hv[c] - mean; q += d * d; }
-        const float rstd = rsqrtf(wave_sum(q) / (float)n + LN_EPS);
+        const float rstd = rsqrtf(wave_sum(q) * inv_n + LN_EPS);
         const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed_l, (uint64_t)row) : 0u;
         const unsigned lane_gold = (unsigned)(lane * (CO / 2)) * 0x9e3779b1u;  // this lane's first column pair in the mask hash
         float o[CO];
@@ -946,11 +947,11 @@ __global__ __launch_bounds__(RT, 4) void tail_fwd_lc_kernel(const void* __restri
             float sm = 0.0f;
 #pragma unroll
             for (int c = 0; c < CO; ++c) { rv[c] += round_store(o[c], out_bf); sm += rv[c]; }  // x1 + f3 as the stored f3 reads back
-            const float mean2 = wave_sum(sm) / (float)n;
+            const float mean2 = wave_sum(sm) * inv_n;
             float q2 = 0.0f;
 #pragma unroll
             for (int c = 0; c < CO; ++c) { const float d = rv[c] - mean2; q2 += d * d; }
-            const float rstd2 = rsqrtf(wave_sum(q2) / (float)n + LN_EPS);
+            const float rstd2 = rsqrtf(wave_sum(q2) * inv_n + LN_EPS);
             ld_span<CO>(ln.gamma2, (size_t)lane * CO, 0, g2);
             ld_span<CO>(ln.beta2, (size_t)lane * CO, 0, b2);
 #pragma unroll
@@ -985,6 +986,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
     constexpr int bf = FASTG ? 1 : 0;  // compile-time dtype (dout has it too): see tail_fwd_lc_kernel
     (void)bf_rt; (void)dout_bf_rt;
     constexpr int n = 64 * CO, k_in = 64 * CI, Q = CO / 4;
+    constexpr float inv_n = 1.0f / (float)n;
     constexpr int NP = LN2 ? 5 : 3;  // column-sum arrays: dgamma, dbeta, dbias (+ LayerNorm-2's dgamma, dbeta)
     static_assert(CO % 4 == 0, "lane span must be whole float4s");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1043,7 +1045,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
                 accw[(3 * Q + q) * 64] = v3;
                 accw[(4 * Q + q) * 64] = v4;
             }
-            const float n1 = wave_sum(t1) / (float)n, n2 = wave_sum(t2) / (float)n;
+            const float n1 = wave_sum(t1) * inv_n, n2 = wave_sum(t2) * inv_n;
 #pragma unroll
             for (int c = 0; c < CO; ++c) dv[c] = round_store(rstd2 * (tv[c] - n1 - sv[c] * n2), bf);
             st_span<CO>(ln.ds, (size_t)row * n + lane * CO, bf, dv);
@@ -1109,7 +1111,7 @@ __global__ __launch_bounds__(RT, 4) void tail_bwd_lc_kernel(const void* __restri
             accw[(1 * Q + q) * 64] = v1;
             __builtin_amdgcn_sched_barrier(0);  // keep the chunks sequential: interleaving them only adds live registers
         }
-        const float m1 = wave_sum(s1v.x + s1v.y) / (float)n, m2 = wave_sum(s2v.x + s2v.y) / (float)n;
+        const float m1 = wave_sum(s1v.x + s1v.y) * inv_n, m2 = wave_sum(s2v.x + s2v.y) * inv_n;
         float o[CO];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -1197,6 +1199,7 @@ __global__ __launch_bounds__(RT) void tail_wide_fwd_kernel(const void* __restric
                                                            const float* __restrict__ beta, void* __restrict__ out, float* __restrict__ mean_o,
                                                            float* __restrict__ rstd_o, int rows, float p_drop, uint64_t seed) {
     constexpr int n = RW * 64 * WCO, k_in = n / WR;
+    constexpr float inv_n = 1.0f / (float)n;
     __shared__ float red[2][2][RW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col0 = (wave * 64 + lane) * WCO, in0 = (wave * 64 + lane) * WCI;
@@ -1223,7 +1226,7 @@ __global__ __launch_bounds__(RT) void tail_wide_fwd_kernel(const void* __restric
         float tot = 0.0f;
 #pragma unroll
         for (int w = 0; w < RW; ++w) tot += red[par][0][w];
-        const float mean = tot / (float)n;
+        const float mean = tot * inv_n;
         float q = 0.0f;
 #pragma unroll
         for (int c = 0; c < WCO; ++c) { const float d = hv[c] - mean; q += d * d; }
@@ -1233,7 +1236,7 @@ __global__ __launch_bounds__(RT) void tail_wide_fwd_kernel(const void* __restric
         float qt = 0.0f;
 #pragma unroll
         for (int w = 0; w < RW; ++w) qt += red[par][1][w];
-        const float rstd = rsqrtf(qt / (float)n + LN_EPS);
+        const float rstd = rsqrtf(qt * inv_n + LN_EPS);
         const unsigned rkey = p_drop > 0.0f ? dropout_row_key(seed_l, (uint64_t)row) : 0u;
         float o[WCO];
 #pragma unroll
@@ -1257,6 +1260,7 @@ __global__ __launch_bounds__(RT) void tail_wide_bwd_kernel(const void* __restric
                                                            float* __restrict__ partials, int rows, float p_drop, uint64_t seed,
                                                            const void* __restrict__ dx_add) {
     constexpr int n = RW * 64 * WCO, k_in = n / WR;
+    constexpr float inv_n = 1.0f / (float)n;
     __shared__ float red[2][2][RW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col0 = (wave * 64 + lane) * WCO, in0 = (wave * 64 + lane) * WCI;
@@ -1309,8 +1313,8 @@ __global__ __launch_bounds__(RT) void tail_wide_bwd_kernel(const void* __restric
         float m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
         for (int w = 0; w < RW; ++w) { m1 += red[par][0][w]; m2 += red[par][1][w]; }
-        m1 /= (float)n;
-        m2 /= (float)n;
+        m1 *= inv_n;
+        m2 *= inv_n;
         float o[WCO];
 #pragma unroll
         for (int c = 0; c < WCO; ++c) {
