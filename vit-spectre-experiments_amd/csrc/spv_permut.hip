@@ -348,6 +348,97 @@ __global__ __launch_bounds__(PT) void gather_bwd_c16_kernel(const bf16_t* __rest
     }
 }
 
+// backward, compact table, LDS-DMA double buffer (bf16, d * 2 % 1024 == 0): ONE 1024-thread workgroup per CU owns two 66.5 KB slice
+// buffers and walks (sample, head) items; the next item's slice is on its way into the other buffer (global_load_lds: no registers,
+// which is what a register-staged prefetch could not afford) while this item's is gathered.  Each wave's table reads are issued
+// BEFORE its DMA pieces so that the in-order memory counter lets the gather start while the DMA is still in flight.
+__global__ __launch_bounds__(PT) void gather_bwd_dma_kernel(const bf16_t* __restrict__ dg, const uint16_t* __restrict__ inv16,
+                                                            const uint8_t* __restrict__ sg8, bf16_t* __restrict__ dx, int heads, int d,
+                                                            int batch) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int slice_bytes = d * 2;                         // multiple of 1024
+    const int pieces = slice_bytes >> 10;                  // 1-KiB wave pieces per slice
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nv = d >> 3;
+    const int per_wg = (batch + gridDim.x - 1) / gridDim.x;   // consecutive samples of this workgroup
+    const int b_begin = blockIdx.x * per_wg, b_end = min(batch, b_begin + per_wg);
+    const int items = (b_end - b_begin) * heads;
+    if (items <= 0) return;
+    auto dma = [&](int item, int buf) {
+        const int b = b_begin + item / heads, h = item % heads;
+        const unsigned char* src = reinterpret_cast<const unsigned char*>(dg + ((size_t)b * heads + h) * d);
+        for (int p = wave; p < pieces; p += PT / 64)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(smem + (size_t)buf * slice_bytes + (size_t)p * 1024), 16, 0, 0);
+    };
+    float acc[C_IT][8];
+#pragma unroll
+    for (int it = 0; it < C_IT; ++it)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[it][k] = 0.0f;
+    // Table entries travel one item ahead as well, and are issued BEHIND that item's DMA pieces: the memory counter retires in order,
+    // so the wait for the entries (the copy below) is also the wait for the slice -- and nothing younger is in flight at that point.
+    uint4 id_n[C_IT];
+    uint32_t sg_n[C_IT];
+    auto fetch_ids = [&](int item) {
+        const int h = item % heads;
+        const uint4* ih = reinterpret_cast<const uint4*>(inv16 + (size_t)h * d);
+        const uint8_t* sh = sg8 + (((size_t)h * d) >> 3);
+#pragma unroll
+        for (int it = 0; it < C_IT; ++it) {
+            const int o = min(it * PT + tid, nv - 1);
+            id_n[it] = ih[o];
+            sg_n[it] = sh[o];
+        }
+    };
+    dma(0, 0);
+    fetch_ids(0);
+    for (int item = 0; item < items; ++item) {
+        const int h = item % heads;
+        uint4 id[C_IT];
+        uint32_t sg[C_IT];
+#pragma unroll
+        for (int it = 0; it < C_IT; ++it) {
+            id[it] = id_n[it];
+            sg[it] = sg_n[it];
+            asm volatile("" : "+v"(id[it].x), "+v"(id[it].y), "+v"(id[it].z), "+v"(id[it].w), "+v"(sg[it]));   // pin the wait here
+        }
+        __syncthreads();   // every wave's pieces of this item have landed, and every wave is done with the other buffer
+        if (item + 1 < items) {
+            dma(item + 1, (item + 1) & 1);
+            fetch_ids(item + 1);
+        }
+        const uint16_t* slice = reinterpret_cast<const uint16_t*>(smem + (size_t)(item & 1) * slice_bytes);
+#pragma unroll
+        for (int it = 0; it < C_IT; ++it) {
+            const int o = it * PT + tid;
+            if (o < nv) {
+                const uint32_t e[8] = {id[it].x & 0xffffu, id[it].x >> 16, id[it].y & 0xffffu, id[it].y >> 16,
+                                       id[it].z & 0xffffu, id[it].z >> 16, id[it].w & 0xffffu, id[it].w >> 16};
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    acc[it][k] += __uint_as_float(((uint32_t)slice[e[k]] << 16) ^ ((sg[it] << (31 - k)) & 0x80000000u));
+            }
+        }
+        if (h == heads - 1) {   // the sample is complete
+            bf16_t* out = dx + (size_t)(b_begin + item / heads) * d;
+#pragma unroll
+            for (int it = 0; it < C_IT; ++it) {
+                const int o = it * PT + tid;
+                if (o < nv) {
+                    uint4 w;
+                    w.x = pack_bf16x2(acc[it][0], acc[it][1]); w.y = pack_bf16x2(acc[it][2], acc[it][3]);
+                    w.z = pack_bf16x2(acc[it][4], acc[it][5]); w.w = pack_bf16x2(acc[it][6], acc[it][7]);
+                    reinterpret_cast<uint4*>(out)[o] = w;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[it][k] = 0.0f;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // idx: spv_permut_table_words(heads, d) uint32 words: [2][heads][d] wide tables ([0] forward, [1] inverse), then -- when
@@ -429,7 +520,14 @@ extern "C" int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* 
     const size_t es = dtype == SPV_BF16 ? 2 : 4;
     const bool aligned = ((size_t)d * es) % 16 == 0 && d % 4 == 0;
     static const bool wide_only = getenv("SPV_PERMUT_WIDE") != nullptr;
-    if (!wide_only && dtype == SPV_BF16 && compact_ok(d) && (size_t)d * 2 <= (size_t)LDS_LIMIT && d <= 8 * PT * C_IT) {
+    static const bool no_dma = getenv("SPV_GATHER_NO_DMA") != nullptr;   // A/B switch
+    if (!wide_only && !no_dma && dtype == SPV_BF16 && compact_ok(d) && ((size_t)d * 2) % 1024 == 0 && (size_t)d * 4 <= (size_t)LDS_LIMIT &&
+        d <= 8 * PT * C_IT && (((uintptr_t)dg | (uintptr_t)dx) & 15) == 0) {
+        const Compact c = compact_of(idx, (int64_t)heads * d);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_bwd_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        const int wgs = std::min(batch, 256);
+        hipLaunchKernelGGL(gather_bwd_dma_kernel, dim3(wgs), dim3(PT), (size_t)d * 4, st, (const bf16_t*)dg, c.inv16, c.inv_sg, (bf16_t*)dx, heads, d, batch);
+    } else if (!wide_only && dtype == SPV_BF16 && compact_ok(d) && (size_t)d * 2 <= (size_t)LDS_LIMIT && d <= 8 * PT * C_IT) {
         const Compact c = compact_of(idx, (int64_t)heads * d);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_bwd_c16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         hipLaunchKernelGGL(gather_bwd_c16_kernel, dim3(batch), dim3(PT), (size_t)d * 2, st, (const bf16_t*)dg, c.inv16, c.inv_sg, (bf16_t*)dx, heads, d);
