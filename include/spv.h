@@ -104,7 +104,7 @@ int spv_set_reserved_cus(int n);
  * ds_read_b64_tr_b16); M, N, lda, ldb multiples of 8; split-K as above. */
 int spv_gemm_tn(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
                 int accumulate, int splits, void* workspace, void* stream);
-/* The same, with up to six folds of row kernels' per-workgroup partial column sums riding in the split-K reduce launch as extra
+/* The same, with up to sixteen folds of row kernels' per-workgroup partial column sums riding in the split-K reduce launch as extra
  * workgroups: out[p][c] = sum_w partials[w][p][c], p < nsum <= 5 (dgamma, dbeta, dbias[, dgamma2, dbeta2]), c < n, fixed order.
  * The row kernel (spv_spectre_tail_bwd*, spv_spectre_tail_ln_bwd, spv_fnet_ln_bwd) is then called with its parameter-gradient
  * pointers NULL: it writes the partials and launches no fold (parts = spv_tail_bwd_parts(rows) for the tails, batch for the FNet
@@ -116,11 +116,23 @@ typedef struct spv_fold_job {
     int parts, nsum, n;
 } spv_fold_job;
 int spv_tail_bwd_parts(int rows);
-/* Folds with no reduce to ride in: up to any number of jobs in one launch per six (the end-of-backward flush of folds that were
- * held back for a later spv_gemm_tn_fold which never came). */
+/* Folds with no reduce to ride in: up to any number of jobs in one launch per sixteen (the end-of-backward flush of folds that were
+ * held back for a later spv_gemm_tn_fold which never came; sixteen per launch). */
 int spv_fold_multi(const spv_fold_job* folds, int nfolds, void* stream);
 int spv_gemm_tn_fold(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int out_dtype,
                      int accumulate, int splits, void* workspace, const spv_fold_job* folds, int nfolds, void* stream);
+/* Up to 8 weight gradients with the same K (C_i [m_i, n_i] fp32 = A_i[K, lda_i]^T . B_i[K, ldb_i], bf16 operands) in ONE launch
+ * + ONE split-K reduce that also carries up to 16 fold jobs.  workspace: splits * sum(m_i * n_i) floats.  For gradients that
+ * nobody reads before the backward pass is over (spectre_vit/hip_ops.py holds them back; reference: the nn.Linear weight
+ * gradients autograd computes node by node, layers.py:85-101). */
+typedef struct spv_tn_problem {
+    const void* a;
+    const void* b;
+    void* c;
+    int m, n, lda, ldb, ldc;
+} spv_tn_problem;
+int spv_gemm_tn_batch(const spv_tn_problem* probs, int nprob, int K, int splits, void* workspace, const spv_fold_job* folds, int nfolds,
+                      void* stream);
 
 /* ---- SpectreLinear tail: out = dropout(GELU_erf(LayerNorm(h)) + adaptive_avg_pool(x)) ---------
  * spectre_vit/models/spectre/layers.py:85-101 (LN eps 1e-5, nn.GELU exact, AdaptiveAvgPool1d over the

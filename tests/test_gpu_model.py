@@ -447,4 +447,61 @@ def test_held_folds_give_the_same_gradients():
     finally:
         hip_ops._hold_fold = orig
     for k in plain:
-        assert torch.equal(plain[k], sunk[k]), k
+        if plain[k].dim() == 2 and "local_head.0.weight" in k and "encoder_blocks" in k:
+            # the layers' weight gradients were held too and computed in ONE batched launch (hip_ops._hold_wgrad): other K-slices,
+            # i.e. another association of the same fp32 sum
+            err = (plain[k] - sunk[k]).norm().item() / plain[k].norm().item()
+            assert err < 2e-6, (k, err)
+        else:
+            assert torch.equal(plain[k], sunk[k]), k
+
+
+def test_held_weight_gradients_run_as_one_batch():
+    """With sink slots the encoder layers' weight gradients are held back and computed by ONE spv_gemm_tn_batch launch when the
+    backward pass ends (hip_ops._hold_wgrad); SPV_WGRAD_BATCH=0 semantics (every gradient by its own launch) must give the same
+    numbers to fp32 re-association, nothing may stay held, and the batch must really have happened."""
+    from spectre_vit import _native, hip_ops
+    from spectre_vit.dp import GradReducer
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    cfg = dict(img_size=32, patch_size=4, in_channels=3, num_classes=100, embed_dim=512, num_encoders=3, num_heads=16, hidden_dim=768,
+               dropout=0.0, activation="gelu", mixer="fft")
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(6)
+    img = torch.randn(96, 3, 32, 32, generator=g).to(d)
+    labels = torch.randint(0, 100, (96,), generator=g).to(d)
+    calls = []
+    orig_call = _native.call
+
+    def spy(name, *a):
+        if name == "spv_gemm_tn_batch":
+            calls.append(a[1])   # problems in the launch
+        return orig_call(name, *a)
+
+    def grads(hold):
+        torch.manual_seed(11)
+        m = SpectreViT(**cfg).to(d).train()
+        red = GradReducer(m, always=True)
+        red.zero_grad()
+        hip_ops._WGRAD_HOLD = hold
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(img)
+        torch.nn.functional.cross_entropy(out, labels).backward()
+        red.finish()
+        assert not hip_ops._held_wgrads and not hip_ops._held_folds
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+    keep = hip_ops._WGRAD_HOLD
+    _native.call = spy
+    hip_ops._native.call = spy
+    try:
+        single = grads(False)
+        assert not calls
+        batched = grads(True)
+        assert calls == [6], calls     # 3 layers x (linear1, linear3) in one launch
+    finally:
+        _native.call = orig_call
+        hip_ops._native.call = orig_call
+        hip_ops._WGRAD_HOLD = keep
+    for k in single:
+        err = (single[k] - batched[k]).norm().item() / max(single[k].norm().item(), 1e-30)
+        assert err < 2e-6, (k, err)

@@ -19,7 +19,10 @@ def main():
     p = lambda t: t.data_ptr()  # noqa: E731
     st = torch.cuda.current_stream().cuda_stream
     iters = 100
-    for (M, N, K, splits_list) in ((768, 512, 33280, (8, 10, 13, 20)), (512, 768, 33280, (10,)), (512, 8192, 33280, (1,)), (256, 128, 640, (1, 2))):
+    cases = ((768, 512, 33280, (8, 10, 13, 20)), (512, 768, 33280, (10,)), (512, 8192, 33280, (1,)), (256, 128, 640, (1, 2)))
+    if len(sys.argv) >= 5:   # M N K s1,s2,...
+        cases = ((int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), tuple(int(v) for v in sys.argv[4].split(","))),)
+    for (M, N, K, splits_list) in cases:
         g = torch.Generator().manual_seed(M + N)
         A = (torch.randn(K, M, generator=g) * 0.5).to(bf).to(dev)
         Bm = (torch.randn(K, N, generator=g) * 0.5).to(bf).to(dev)

@@ -857,22 +857,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// one 128 x 128 tile of one K-slice (the body of gemm_tn_kernel and of the batched form below)
 template <typename TO, int DEPTH>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                      TO* __restrict__ C, float* __restrict__ ws, int M, int N, int K, int lda,
-                                                      int ldb, int ldc, int k_per_split, int accumulate, int tiles_n,
-                                                      int tiles_mn, int nsplit) {
+__device__ __forceinline__ void tn_tile_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
+                                             float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc, int k_per_split,
+                                             int accumulate, int tiles_n, int tile, int split) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TBK * TROWB];  // 40 960 B (>= the epilogue's 36 864 B)
     unsigned char* sA = smem;
     unsigned char* sB = smem + TBK * TROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // one linear id over (split, tile), XCD-remapped as a whole: each XCD gets whole K-slices, so the tiles that
-    // share a slice's operand rows hit in that XCD's L2 (per-slice round-robin made every XCD fetch every slice:
-    // 3.4x the algorithmic HBM reads on the weight-gradient GEMM, FETCH_SIZE)
-    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);
-    const int split = lin / tiles_mn;
-    const int tile = lin % tiles_mn;
     const int tm = tile / tiles_n, tn = tile % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = split * k_per_split;
@@ -955,6 +949,45 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
         for (int k0 = kbeg; k0 < kend; k0 += TBK) step(k0, ra0, rb0);
     }
     store_acc_tile<TO>(acc, smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr);
+}
+
+template <typename TO, int DEPTH>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                      TO* __restrict__ C, float* __restrict__ ws, int M, int N, int K, int lda,
+                                                      int ldb, int ldc, int k_per_split, int accumulate, int tiles_n,
+                                                      int tiles_mn, int nsplit) {
+    // one linear id over (split, tile), XCD-remapped as a whole: each XCD gets whole K-slices, so the tiles that
+    // share a slice's operand rows hit in that XCD's L2 (per-slice round-robin made every XCD fetch every slice:
+    // 3.4x the algorithmic HBM reads on the weight-gradient GEMM, FETCH_SIZE)
+    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);
+    tn_tile_body<TO, DEPTH>(A, B, C, ws, M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, lin % tiles_mn, lin / tiles_mn);
+}
+
+// Several weight gradients with the same K (the rows of the batch) in ONE launch: the layer weight gradients are 24 tiles each, so
+// alone each needs ~21 K-slices to fill the chip (a 25-K-tile loop per workgroup, 33 MB of partial sums written and re-read);
+// eight of them together fill it with 5 slices of 104 K-tiles.  Isolated: 8 x 53 us -> 307 us (emulated as one 768 x 4096 x 33280
+// problem).  Only for gradients nobody reads before the backward pass ends (hip_ops._held_wgrads).
+constexpr int TNB_MAX = 8;
+struct TnBatch {
+    int nprob;
+    int first_tile[TNB_MAX + 1];
+    long long ws_off[TNB_MAX];   // floats into the workspace: nsplit slabs of M x N per problem, problem after problem
+    struct P {
+        const bf16_t* A;
+        const bf16_t* B;
+        float* C;
+        int M, N, lda, ldb, ldc, tiles_n;
+    } p[TNB_MAX];
+};
+__global__ __launch_bounds__(256) void gemm_tn_batch_kernel(TnBatch tb, float* __restrict__ ws, int K, int k_per_split, int nsplit) {
+    const int total = tb.first_tile[tb.nprob];
+    const int lin = xcd_remap(blockIdx.x, total * nsplit);
+    const int split = lin / total, t = lin % total;
+    int j = 0;
+    while (j + 1 < tb.nprob && t >= tb.first_tile[j + 1]) ++j;   // workgroup-uniform
+    const TnBatch::P& q = tb.p[j];
+    tn_tile_body<float, 3>(q.A, q.B, q.C, ws + tb.ws_off[j], q.M, q.N, K, q.lda, q.ldb, q.ldc, k_per_split, 0, q.tiles_n,
+                           t - tb.first_tile[j], split);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1304,7 +1337,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // between two large kernels costs the step ~20 us (eight per-layer fold launches removed: 157 us), so folds travel with launches that
 // happen anyway.  (Keeping the split-K SUMS back until the end of the backward as well was measured and dropped: 2.09 -> 2.23 ms --
 // eight 33 MB workspaces outlive their stay in the 256 MB MALL and the late sum reads them from HBM.)
-constexpr int FJ_MAX = 6;
+constexpr int FJ_MAX = 16;
 struct FoldJobs {
     int njobs;
     int first_block[FJ_MAX + 1];
@@ -1331,6 +1364,20 @@ __global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void splitk_reduce_fold_kern
         // a quarter of the block's threads each: the sum has 98 k four-column quads at the layer shapes -- as 1024-thread blocks that is
         // 96 workgroups for 256 CUs; as 256 live threads per block, 384
         splitk_reduce_body<TO>(ws, nullptr, C, M, N, ldc, splits, accumulate, blockIdx.x - fold_blocks, reduce_blocks, threadIdx.x, 256);
+}
+
+// the split-K sums of a batch (gemm_tn_batch_kernel) + folds, one launch: folds first, then reduce_blocks workgroups per problem
+__global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void splitk_reduce_batch_kernel(TnBatch tb, const float* __restrict__ ws, int splits,
+                                                                                    int reduce_blocks, FoldJobs fj) {
+    const int fold_blocks = fj.njobs > 0 ? fj.first_block[fj.njobs] : 0;
+    if ((int)blockIdx.x < fold_blocks) {
+        fold_jobs_block(fj, (int)blockIdx.x, threadIdx.x);
+    } else if (threadIdx.x < 256) {
+        const int b = (int)blockIdx.x - fold_blocks;
+        const int j = b / reduce_blocks;
+        const TnBatch::P& q = tb.p[j];
+        splitk_reduce_body<float>(ws + tb.ws_off[j], nullptr, q.C, q.M, q.N, q.ldc, splits, 0, b % reduce_blocks, reduce_blocks, threadIdx.x, 256);
+    }
 }
 
 inline int kend_len(int K, int k_per_split) { return K < k_per_split ? K : k_per_split; }
@@ -1544,6 +1591,7 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
     // the training step it measured SLOWER (68 vs 47 us per launch), so the register-staged kernel stays the default
     static const int use_dma = getenv("SPV_TN_DMA") ? atoi(getenv("SPV_TN_DMA")) : 0;
     static const int use_wide = getenv("SPV_TN_WIDE") ? atoi(getenv("SPV_TN_WIDE")) : 1;
+    static const int wide_min = getenv("SPV_TN_WIDE_MIN") ? atoi(getenv("SPV_TN_WIDE_MIN")) : 4;   // tuning aid
     if (use_dma && M % BM == 0 && N % BN == 0 && K % TDK == 0 && k_per_split % TDK == 0 && (ws != nullptr || ldc % 4 == 0)) {
         const int nwg = tiles_m * tiles_n * splits;
         if (out_dtype == SPV_BF16) {
@@ -1557,7 +1605,7 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
         }
         SPV_LAUNCH_CHECK("spv_gemm_tn(dma)");
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN_DMA);
-    } else if (use_wide && splits >= 4 && M % TWM == 0 && N % BN == 0 && (M / TWM) * tiles_n * splits >= 128) {
+    } else if (use_wide && splits >= wide_min && M % TWM == 0 && N % BN == 0 && (M / TWM) * tiles_n * splits >= 128) {
         // the 256 x 128 tile (8 waves, one workgroup per CU): the split-K layer weight gradients (SPV_TN_WIDE=0 for the 128 x 128
         // kernel).  Measured in graph mode, alternating: 2.372 vs 2.385 ms/step -- 1.6 us per launch; without split-K (the MHPermutMix
         // weight gradient, 512 x 8192 x 33 280) it is SLOWER (651 vs 510 us), hence splits >= 4
@@ -1641,5 +1689,45 @@ extern "C" int spv_fold_multi(const spv_fold_job* folds, int nfolds, void* strea
         hipLaunchKernelGGL(fold_multi_kernel, dim3(blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, fj);
         SPV_LAUNCH_CHECK("spv_fold_multi");
     }
+    return 0;
+}
+
+extern "C" int spv_gemm_tn_batch(const spv_tn_problem* probs, int nprob, int K, int splits, void* workspace, const spv_fold_job* folds,
+                                 int nfolds, void* stream) {
+    SPV_CHECK(probs != nullptr && nprob >= 1 && nprob <= TNB_MAX, "spv_gemm_tn_batch: 1..%d problems", TNB_MAX);
+    SPV_CHECK(K > 0 && splits >= 1 && workspace != nullptr, "spv_gemm_tn_batch: K=%d splits=%d need a workspace", K, splits);
+    SPV_CHECK(nfolds >= 0 && nfolds <= FJ_MAX && (nfolds == 0 || folds != nullptr), "spv_gemm_tn_batch: 0..%d fold jobs", FJ_MAX);
+    TnBatch tb{};
+    tb.nprob = nprob;
+    int tiles = 0;
+    long long off = 0;
+    int k_per_split = cdiv(cdiv(K, splits), TBK) * TBK;
+    splits = cdiv(K, k_per_split);
+    int reduce_blocks = 1;
+    for (int i = 0; i < nprob; ++i) {
+        const spv_tn_problem& q = probs[i];
+        SPV_CHECK(q.a != nullptr && q.b != nullptr && q.c != nullptr && q.m > 0 && q.n > 0, "spv_gemm_tn_batch: empty problem %d", i);
+        SPV_CHECK(q.m % 8 == 0 && q.n % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.lda >= q.m && q.ldb >= q.n && q.ldc >= q.n,
+                  "spv_gemm_tn_batch: problem %d: M=%d N=%d lda=%d ldb=%d ldc=%d (multiples of 8, leading dimensions >= extents)", i, q.m, q.n,
+                  q.lda, q.ldb, q.ldc);
+        SPV_CHECK(((uintptr_t)q.a & 15) == 0 && ((uintptr_t)q.b & 15) == 0, "spv_gemm_tn_batch: problem %d: A/B must be 16-byte aligned", i);
+        tb.first_tile[i] = tiles;
+        tb.ws_off[i] = off;
+        tb.p[i] = {static_cast<const bf16_t*>(q.a), static_cast<const bf16_t*>(q.b), static_cast<float*>(q.c), q.m, q.n, q.lda, q.ldb, q.ldc, cdiv(q.n, BN)};
+        tiles += cdiv(q.m, BM) * cdiv(q.n, BN);
+        off += (long long)splits * q.m * q.n;
+        reduce_blocks = std::max(reduce_blocks, (int)std::min<int64_t>(((int64_t)q.m * q.n / ((q.n & 3) == 0 ? 4 : 1) + 255) / 256, 2048));
+    }
+    tb.first_tile[nprob] = tiles;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    SPV_COUNT_PATH(SPV_PATH_GEMM_TN);
+    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+    SPV_LAUNCH_CHECK("spv_gemm_tn_batch");
+    FoldJobs fj{};
+    int fold_blocks = 0;
+    SPV_CHECK(fill_fold_jobs(folds, nfolds, fj, fold_blocks) == 0, "spv_gemm_tn_batch: bad fold job");
+    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(fold_blocks + nprob * reduce_blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, tb,
+                       static_cast<const float*>(workspace), splits, reduce_blocks, fj);
+    SPV_LAUNCH_CHECK("spv_gemm_tn_batch(split-k reduce + fold)");
     return 0;
 }

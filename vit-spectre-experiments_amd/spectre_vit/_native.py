@@ -57,6 +57,7 @@ SIGNATURES = {
     "spv_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_f, c_u64, c_i, c_vp],
     "spv_fold_multi": [c_vp, c_i, c_vp],
     "spv_gemm_tn_fold": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_i, c_vp],
+    "spv_gemm_tn_batch": [c_vp, c_i, c_i, c_i, c_vp, c_vp, c_i, c_vp],
     "spv_small_sl_supported": [c_i, c_i, c_i],
     "spv_small_sl_partial_floats": [c_i, c_i],
     "spv_small_sl_fwd": [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
@@ -103,6 +104,11 @@ _NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_tail
 class FoldJob(ctypes.Structure):
     """spv_fold_job (include/spv.h): the fold of a tail backward's partial column sums, handed to spv_gemm_tn_fold"""
     _fields_ = [("partials", c_vp), ("out", c_vp * 5), ("parts", c_i), ("nsum", c_i), ("n", c_i)]
+
+
+class TnProblem(ctypes.Structure):
+    """spv_tn_problem (include/spv.h): one weight gradient of a spv_gemm_tn_batch launch"""
+    _fields_ = [("a", c_vp), ("b", c_vp), ("c", c_vp), ("m", c_i), ("n", c_i), ("lda", c_i), ("ldb", c_i), ("ldc", c_i)]
 
 
 _lib = None

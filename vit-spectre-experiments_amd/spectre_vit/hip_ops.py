@@ -396,7 +396,15 @@ def join_side_stream():
 # ------------------------------------------------------------------------------------------------
 _held_folds = []   # (partials, outputs, parts, n)
 _held_task = -2    # the autograd graph task (backward pass) the held folds belong to
-FOLD_RIDERS = 6    # fold jobs one reduce launch carries (csrc/spv_gemm.hip FJ_MAX)
+FOLD_RIDERS = 6    # fold jobs a layer's own reduce launch carries
+# Layer weight gradients travel together as well: alone each is 24 tiles of 128 x 128, i.e. ~21 K-slices to fill the chip (25 K-tiles
+# per workgroup, 33 MB of partial sums written and re-read); eight of them in one launch fill it with 5 slices.  Same conditions as a
+# held fold (sink-backed outputs, one process), and only gradients nothing reads before the backward pass ends.
+_held_wgrads = []  # (dh, x, dw address, rows, n, k, fold or None)
+WGRAD_BATCH = 8    # problems per launch (csrc/spv_gemm.hip TNB_MAX)
+BATCH_FOLDS = 16   # fold jobs the batch's reduce launch carries (FJ_MAX)
+_WGRAD_HOLD = os.environ.get("SPV_WGRAD_BATCH", "1") != "0"
+_WGRAD_SPLITS = int(os.environ.get("SPV_WGRAD_BATCH_SPLITS", "0"))   # tuning aid: 0 = chosen per batch
 
 
 def _hold_ok():
@@ -416,9 +424,68 @@ def _fold_array(folds):
     return arr
 
 
-def flush_held_folds():
-    """run the folds still held (called by the autograd engine when the backward pass is over)"""
+def _batch_splits(tiles):
+    """K-slices of a batch of `tiles` 128 x 128 tiles: the count whose workgroups fill whole rounds of the chip's ~512 slots (two
+    4-wave workgroups per CU) best; measured on 192 tiles: 5 slices (960 workgroups) 307 us, 2: 321, 4: 355, 3: 396"""
+    if _WGRAD_SPLITS > 0:
+        return _WGRAD_SPLITS
+    best, best_score = 1, -1.0
+    for sp in range(1, 11):
+        rounds = tiles * sp / 512.0
+        score = rounds / max(1.0, float(-(-tiles * sp // 512))) - 0.01 * sp
+        if rounds >= 0.7 and score > best_score:
+            best, best_score = sp, score
+    return best
+
+
+def _flush_held_wgrads():
+    """the weight gradients held back during this backward pass: one launch (+ one reduce that carries their folds and the folds held
+    so far) per group of up to eight with the same row count"""
+    while _held_wgrads:
+        rows = _held_wgrads[0][3]
+        group = [w for w in _held_wgrads if w[3] == rows][:WGRAD_BATCH]
+        for w in group:
+            _held_wgrads.remove(w)
+        probs = (_native.TnProblem * len(group))()
+        tiles = floats = 0
+        folds = []
+        for q, (dh, x, dwp, _, n, k, fold) in zip(probs, group):
+            q.a, q.b, q.c, q.m, q.n, q.lda, q.ldb, q.ldc = _p(dh), _p(x), dwp, n, k, n, k, k
+            tiles += ((n + 127) // 128) * ((k + 127) // 128)
+            floats += n * k
+            if fold is not None:
+                folds.append(fold)
+        while _held_folds and len(folds) < BATCH_FOLDS:
+            folds.append(_held_folds.pop(0))
+        splits = _batch_splits(tiles)
+        ws = torch.empty((splits * floats,), dtype=torch.float32, device=group[0][0].device)
+        arr = _fold_array(folds) if folds else None
+        _native.call("spv_gemm_tn_batch", ctypes.addressof(probs), len(group), rows, splits, _p(ws), ctypes.addressof(arr) if folds else 0,
+                     len(folds), _stream())
+
+
+def _hold_wgrad(dh, x, dw, sink, rows, n, k, fold, fold_sunk):
+    """hold a layer weight gradient for the batch launch at the end of this backward pass (see _held_wgrads).  False: not held."""
     global _held_task
+    if not (_WGRAD_HOLD and _hold_ok() and sink is not None and dw.data_ptr() == sink.view.data_ptr() and (fold is None or fold_sunk)):
+        return False
+    task = torch._C._current_graph_task_id()
+    if task < 0:
+        return False
+    if _held_task != task:
+        _held_folds.clear()
+        _held_wgrads.clear()
+        torch.autograd.Variable._execution_engine.queue_callback(flush_held_folds)
+        _held_task = task
+    f = None if fold is None else (fold[0], tuple(o.data_ptr() for o in fold[1]), fold[2], fold[3])   # raw sink addresses, as _hold_fold
+    _held_wgrads.append((dh, x, dw.data_ptr(), rows, n, k, f))
+    return True
+
+
+def flush_held_folds():
+    """run the weight gradients and folds still held (called by the autograd engine when the backward pass is over)"""
+    global _held_task
+    _flush_held_wgrads()
     if _held_folds:
         arr = _fold_array(_held_folds)
         _native.call("spv_fold_multi", ctypes.addressof(arr), len(_held_folds), _stream())
@@ -438,6 +505,7 @@ def _hold_fold(partials, outs, sinks, parts, n):
         return False
     if _held_task != task:
         _held_folds.clear()   # leftovers of a backward pass that never finished (an exception): their launch must not ride along
+        _held_wgrads.clear()
         torch.autograd.Variable._execution_engine.queue_callback(flush_held_folds)
         _held_task = task
     _held_folds.append((partials, tuple(o.data_ptr() for o in outs), parts, n))
@@ -456,7 +524,12 @@ def _fold_job(partials, outs, rows, n):
     return (partials, tuple(outs), _native.call("spv_tail_bwd_parts", rows), n)
 
 
-def _weight_grad(dh, x, rows, n, k, sink=None, fold=None):
+def _sunk(outs, sinks):
+    """every gradient tensor IS its parameter's sink slot (memory that outlives the node: its content may be written later)"""
+    return all(sk is not None and o.data_ptr() == sk.view.data_ptr() for o, sk in zip(outs, sinks))
+
+
+def _weight_grad(dh, x, rows, n, k, sink=None, fold=None, fold_sunk=False):
     """dW[n,k] = dh[rows,n]^T . x[rows,k], split-K over rows.  bf16: TN kernel straight from the row-major activations
     (transposing LDS reads); fp32 (parity path): NT kernel over explicit transposes.  fold (a _fold_job, only when
     _fold_rides): the same layer's dgamma / dbeta / dbias fold, run as extra workgroups of the split-K reduce."""
@@ -473,6 +546,8 @@ def _weight_grad(dh, x, rows, n, k, sink=None, fold=None):
         splits = max(1, min(256 // tiles, rows // 64))
     ws = None
     if dh.dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0:
+        if tiles >= 8 and 2.0 * rows * n * k < _SIDE_MIN_FLOPS and _hold_wgrad(dh, x, dw, sink, rows, n, k, fold, fold_sunk):
+            return dw   # computed with the other layers' at the end of the backward pass
         def launch(riders=True):
             nonlocal ws
             if ws is None and splits > 1:
@@ -592,7 +667,8 @@ def _sl_backward(dout2, saved, need_dx=True, dx_add=None, up=None):
         _native.call("spv_spectre_tail_bwd", _p(dout2), _p(h), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(dh), _p(dx),
                      pg, pb, pbi, _p(partials), rows, n, k, _dt(h), _dt(dout2), p_drop, seed,
                      _p(dx_add) if need_dx else 0, _stream())
-    dw = _weight_grad(dh, x2, rows, n, k, s_w, _fold_job(partials, (dgamma, dbeta, dbias), rows, n) if ride else None)
+    dw = _weight_grad(dh, x2, rows, n, k, s_w, _fold_job(partials, (dgamma, dbeta, dbias), rows, n) if ride else None,
+                      ride and _sunk((dgamma, dbeta, dbias), (s_g, s_be, s_b)))
     if need_dx:
         _gemm(dh, wt, None, dx, rows, k, n, n, wt.shape[1], k, accumulate=1)
     else:
@@ -1343,7 +1419,8 @@ class FFResidualFn(torch.autograd.Function):
             _native.call("spv_spectre_tail_ln_bwd", _p(d2), _p(f3), _p(x1), _p(mean2), _p(rstd2), _p(n2w), _p(ds), pp(dn2w), pp(dn2b),
                          _p(h3), _p(mean3), _p(rstd3), _p(g3), _p(be3), _p(dh3), 0 if defer else _p(df1), pp(dg3), pp(dbe3), pp(db3),
                          _p(partials), rows, n, k, _dt(h3), p_drop, seed, _stream())
-            dw3 = _weight_grad(dh3, f1, rows, n, k, s_w, _fold_job(partials, (dg3, dbe3, db3, dn2w, dn2b), rows, n) if ride else None)
+            dw3 = _weight_grad(dh3, f1, rows, n, k, s_w, _fold_job(partials, (dg3, dbe3, db3, dn2w, dn2b), rows, n) if ride else None,
+                               ride and _sunk((dg3, dbe3, db3, dn2w, dn2b), (s_g, s_be, s_b, sinks2[0], sinks2[1])))
             _gemm(dh3, wt3, None, df1, rows, k, n, n, wt3.shape[1], k, accumulate=0 if defer else 1)
             if defer:
                 dx1, dw1, db1, dg1, dbe1 = _sl_backward(df1, s1, True, dx_add=ds, up=(ds, p_drop, seed))
