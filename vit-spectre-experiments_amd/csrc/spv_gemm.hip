@@ -1372,11 +1372,12 @@ __global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void splitk_reduce_batch_ker
     const int fold_blocks = fj.njobs > 0 ? fj.first_block[fj.njobs] : 0;
     if ((int)blockIdx.x < fold_blocks) {
         fold_jobs_block(fj, (int)blockIdx.x, threadIdx.x);
-    } else if (threadIdx.x < 256) {
+    } else {   // all 1024 threads sum (eight problems are 786 k four-column quads: 768 workgroups)
         const int b = (int)blockIdx.x - fold_blocks;
         const int j = b / reduce_blocks;
         const TnBatch::P& q = tb.p[j];
-        splitk_reduce_body<float>(ws + tb.ws_off[j], nullptr, q.C, q.M, q.N, q.ldc, splits, 0, b % reduce_blocks, reduce_blocks, threadIdx.x, 256);
+        splitk_reduce_body<float>(ws + tb.ws_off[j], nullptr, q.C, q.M, q.N, q.ldc, splits, 0, b % reduce_blocks, reduce_blocks, threadIdx.x,
+                                  FOLD_COLS * FOLD_ROWS);
     }
 }
 
@@ -1716,7 +1717,8 @@ extern "C" int spv_gemm_tn_batch(const spv_tn_problem* probs, int nprob, int K, 
         tb.p[i] = {static_cast<const bf16_t*>(q.a), static_cast<const bf16_t*>(q.b), static_cast<float*>(q.c), q.m, q.n, q.lda, q.ldb, q.ldc, cdiv(q.n, BN)};
         tiles += cdiv(q.m, BM) * cdiv(q.n, BN);
         off += (long long)splits * q.m * q.n;
-        reduce_blocks = std::max(reduce_blocks, (int)std::min<int64_t>(((int64_t)q.m * q.n / ((q.n & 3) == 0 ? 4 : 1) + 255) / 256, 2048));
+        constexpr int RT = FOLD_COLS * FOLD_ROWS;
+        reduce_blocks = std::max(reduce_blocks, (int)std::min<int64_t>(((int64_t)q.m * q.n / ((q.n & 3) == 0 ? 4 : 1) + RT - 1) / RT, 2048));
     }
     tb.first_tile[nprob] = tiles;
     hipStream_t st = static_cast<hipStream_t>(stream);
