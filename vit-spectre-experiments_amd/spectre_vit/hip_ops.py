@@ -405,6 +405,7 @@ WGRAD_BATCH = 8    # problems per launch (csrc/spv_gemm.hip TNB_MAX)
 BATCH_FOLDS = 16   # fold jobs the batch's reduce launch carries (FJ_MAX)
 _WGRAD_HOLD = os.environ.get("SPV_WGRAD_BATCH", "1") != "0"
 _WGRAD_SPLITS = int(os.environ.get("SPV_WGRAD_BATCH_SPLITS", "0"))   # tuning aid: 0 = chosen per batch
+_WGRAD_SIDE = os.environ.get("SPV_WGRAD_SIDE", "1") != "0"            # the batch starts on the side stream beside the embedding's backward
 
 
 def _hold_ok():
@@ -464,6 +465,21 @@ def _flush_held_wgrads():
                      len(folds), _stream())
 
 
+def start_held_wgrads():
+    """Called by the LAST node of the backward pass that does real work (the patch embedding): every layer's weight gradient is held
+    by now, so their batch starts here on the side stream and runs beside the embedding's backward -- a chain of small, latency-bound
+    launches that leaves most of the chip idle.  The end-of-pass callback joins the streams.  True when something was started."""
+    if not (_WGRAD_SIDE and _held_wgrads and _held_task == torch._C._current_graph_task_id()):
+        return False
+    side = _side_stream(_held_wgrads[0][0].device)
+    side.wait_stream(torch.cuda.current_stream())
+    keep = [(w[0], w[1]) for w in _held_wgrads]   # operands of a side-stream kernel: alive until the join
+    with torch.cuda.stream(side):
+        _flush_held_wgrads()
+    _side_keep.extend(keep)
+    return True
+
+
 def _hold_wgrad(dh, x, dw, sink, rows, n, k, fold, fold_sunk):
     """hold a layer weight gradient for the batch launch at the end of this backward pass (see _held_wgrads).  False: not held."""
     global _held_task
@@ -491,6 +507,7 @@ def flush_held_folds():
         _native.call("spv_fold_multi", ctypes.addressof(arr), len(_held_folds), _stream())
         _held_folds.clear()
     _held_task = -2
+    join_side_stream()   # a batch started early by start_held_wgrads
 
 
 def _hold_fold(partials, outs, sinks, parts, n):
@@ -972,6 +989,7 @@ class PatchEmbedFn(torch.autograd.Function):
         dev = dtok.device
         st = _stream()
         dtok = dtok.contiguous()
+        early = start_held_wgrads()   # the layers' weight gradients, one batched launch on the side stream beside everything below
         gcls = _cls_grad_stash.pop(ctx.key, None)   # (B, E): the global residual's CLS-row gradient, not yet added (TapClsFn)
         if gcls is not None:
             gcls = gcls.to(dtok.dtype).contiguous()
@@ -990,7 +1008,8 @@ class PatchEmbedFn(torch.autograd.Function):
             # dW = dtok^T . P over all B*T token rows, with P the patch matrix widened by a zero row per image (the CLS
             # row): the TN kernel then takes dtok as it lies in memory -- no transposed copies of a 34 MB tensor
             dwf = _weight_grad(dtok.view(B * T, E), patches, B * T, E, K)
-            join_side_stream()
+            if not early:   # (with a batch in flight the end-of-pass callback joins: the spectral fold's backward overlaps it too)
+                join_side_stream()
             return None, dwf, dbias, dcls, dpos_full, None, None, None, None
         rows = B * Np
         ld = (rows + 7) // 8 * 8
