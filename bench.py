@@ -124,7 +124,7 @@ def attach_pmc_traffic(roof, mixer):
         return
     data = json.load(open(files[-1]))
     pats = {"gemm": ("gemm_nt_strip", "gemm_nt_kernel", "gemm_nt_glds"), "gemm_acc": ("gemm_nt_strip", "gemm_nt_kernel"), "gemm_tn": ("gemm_tn", "wgrad"),
-            "gemm_pool_bwd": ("gemm_nt_pool", "gemm_nt_kernel"), "fnet_ln_fwd": ("fnet",), "fnet_ln_bwd": ("fnet",),
+            "gemm_pool_bwd": ("gemm_nt_strip", "gemm_nt_pool", "gemm_nt_kernel"), "fnet_ln_fwd": ("fnet",), "fnet_ln_bwd": ("fnet",),
             "fnet_mix": ("fnet",), "tail_fwd": ("tail_fwd",), "tail_bwd": ("tail_bwd",), "tail_bwd_up": ("tail_bwd",),
             "tail_ln_fwd": ("tail_fwd",), "tail_ln_bwd": ("tail_bwd",), "gather_fwd": ("gather_fwd",), "gather_bwd": ("gather_bwd",)}
     want = pats.get(roof["kernel"], (roof["kernel"],))
