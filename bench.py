@@ -389,6 +389,20 @@ def main():
         rec["value"], rec["ms_per_step"], rec["final_loss"] = gr["images_per_sec"], gr["graph_ms_per_step"], gr["final_loss"]
         rec["config"]["launch"] = "one HIP graph per step (spectre_vit.graph.GraphedTrainStep); eager figures under \"eager\""
         rec["graph"] = gr
+        # Exact dead-row elimination, stated with its counterpart: SpectreViT reads only the CLS row of the stack's output (reference
+        # spectre.py:198) and the last layer's feed-forward half works row by row, so by default it runs at the CLS rows only -- same
+        # logits, loss and gradients (tests/test_gpu_bench_shapes.py checks both forms against the oracle).  The same graph-replayed
+        # step with every row computed, as the reference does, is measured beside it.
+        from spectre_vit import hip_ops
+        rec["config"]["last_layer_feed_forward"] = "CLS rows only (exact; SPV_FULL_LAST_LAYER=1 for every row)" if hip_ops.LAST_LAYER_CLS_ONLY else "every row"
+        if hip_ops.LAST_LAYER_CLS_ONLY:
+            hip_ops.LAST_LAYER_CLS_ONLY = False
+            try:
+                full = graph_replay(args, args.mixer, dev, max(5, min(args.steps, 20)), min(args.warmup, 5))
+            finally:
+                hip_ops.LAST_LAYER_CLS_ONLY = True
+            rec["every_row_of_last_layer"] = {"value": full["images_per_sec"], "unit": "images/sec", "ms_per_step": full["graph_ms_per_step"],
+                                              "final_loss": full["final_loss"]}
         if "kernels_coverage" in rec:
             rec["kernels_coverage"]["frac_of_step"] = round(rec["kernels_coverage"]["bracketed_ms_per_step"] / rec["ms_per_step"], 3)
             rec["kernels_coverage"]["note"] = ("sum of bracketed launch durations (eager roofline pass; it brackets the layer weight "

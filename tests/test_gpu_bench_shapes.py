@@ -93,20 +93,29 @@ def run_and_compare(m, img, labels, ref, dtype, what, bound=None):
     return errs
 
 
+@pytest.mark.parametrize("full_last_layer", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_fft_step_at_bench_shapes(dtype):
+def test_fft_step_at_bench_shapes(dtype, full_last_layer):
     """Small / FFT mixer / 4 layers / bs 512 (bench.py's workload, dropout off): logits, loss, CLS features and every parameter
-    gradient vs the float64 oracle."""
-    m, img, labels, sd = _setup(SMALL, "fft", 512, 11)
-    ref = oracle_step("fft512", img, labels, sd, 4, 4, "fft")
-    before = census()
-    run_and_compare(m, img, labels, ref, dtype, "fft bs512")
-    took = {k: census()[k] - before[k] for k in before}
+    gradient vs the float64 oracle -- with the last layer's feed-forward half at the CLS rows only (the default: SpectreViT reads no
+    other row of the stack's output, hip_ops.LAST_LAYER_CLS_ONLY) and over every row, as the reference computes it."""
+    from spectre_vit import hip_ops
+    keep = hip_ops.LAST_LAYER_CLS_ONLY
+    hip_ops.LAST_LAYER_CLS_ONLY = not full_last_layer
+    try:
+        m, img, labels, sd = _setup(SMALL, "fft", 512, 11)
+        ref = oracle_step("fft512", img, labels, sd, 4, 4, "fft")
+        before = census()
+        run_and_compare(m, img, labels, ref, dtype, f"fft bs512{' (every row of the last layer)' if full_last_layer else ''}")
+        took = {k: census()[k] - before[k] for k in before}
+    finally:
+        hip_ops.LAST_LAYER_CLS_ONLY = keep
     if dtype == torch.bfloat16:
-        # the kernels bench.py times: 4 layers x (linear1 + linear3 forward, linear3 dgrad store-form, linear1 dgrad accumulate-form)
-        assert took["gemm_strip"] == 12, took      # linear1 + linear3 forward, linear3 data gradient (store form), per layer
-        assert took["gemm_strip_acc"] == 4, took   # linear1 data gradient (C += form)
-        assert took["gemm_tn"] >= 8, took
+        big = 4 if full_last_layer else 3   # layers whose feed-forward half runs over all 33280 token rows
+        # the kernels bench.py times: per layer linear1 + linear3 forward, linear3 dgrad store-form, linear1 dgrad accumulate-form
+        assert took["gemm_strip"] == 3 * big, took      # linear1 + linear3 forward, linear3 data gradient (store form), per layer
+        assert took["gemm_strip_acc"] == big, took      # linear1 data gradient (C += form)
+        assert took["gemm_tn"] >= 1, took
         assert took["tail_ln"] == 8 and took["tail_up"] == 4, took   # fused linear3 tail + LayerNorm-2 fwd/bwd; skip gradient at source
         assert took["fnet_mfma"] == 8, took                          # fused mixer + LayerNorm-1, forward and backward
 

@@ -458,7 +458,7 @@ def _flush_held_wgrads():
                 folds.append(fold)
         while _held_folds and len(folds) < BATCH_FOLDS:
             folds.append(_held_folds.pop(0))
-        splits = _batch_splits(tiles)
+        splits = max(1, min(_batch_splits(tiles), rows // 256))   # (the CLS-only last layer: 512 rows)
         ws = torch.empty((splits * floats,), dtype=torch.float32, device=group[0][0].device)
         arr = _fold_array(folds) if folds else None
         _native.call("spv_gemm_tn_batch", ctypes.addressof(probs), len(group), rows, splits, _p(ws), ctypes.addressof(arr) if folds else 0,
@@ -1134,12 +1134,35 @@ class TapClsFn(torch.autograd.Function):
 
 
 _cls_grad_bufs = {}
+# SpectreViT reads the CLS row of the stack's output and nothing else (reference spectre.py:198), and everything behind the LAST
+# layer's token mixer works row by row (LayerNorm, SpectreLinear, residual): that layer's feed-forward half only has to exist at the
+# CLS rows -- the same logits, loss and gradients (the other rows' gradients are exactly zero in the reference too).
+# SPV_FULL_LAST_LAYER=1 computes every row, as the reference does.
+LAST_LAYER_CLS_ONLY = os.environ.get("SPV_FULL_LAST_LAYER", "0") == "0"
+
+
+class TakeClsFn(torch.autograd.Function):
+    """x (B, N, E) -> x[:, 0, :] as a contiguous (B, E) tensor.  Backward: the dense gradient that is zero off the CLS row, in the kept
+    buffer of _cls_row_gradient (its consumer, the token mixer's backward, only reads it)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x)
+        ctx.meta = (x.shape, x.dtype)
+        return x[:, 0, :].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, dtype = ctx.meta
+        return _cls_row_gradient(shape, dtype, g.device, g)
 
 
 def _cls_row_gradient(shape, dtype, dev, rows):
     """The stack's output gradient when only the CLS rows carry one: a (B, N, E) tensor that is zero off row 0.  The buffer is kept
     across steps -- nothing ever writes its other rows (the consumers read it; TapClsFn adds in place to row 0 only) -- so a step
     costs the CLS-row copy, not a 34 MB fill."""
+    if shape[1] == 1:   # the stack handed over its CLS rows only (LAST_LAYER_CLS_ONLY): the gradient is those rows
+        return rows.to(dtype).reshape(shape)
     key = (tuple(shape), dtype, dev.index)   # not per stream: a graph capture runs on its own stream and must find the warm-up's buffer
     full = _cls_grad_bufs.get(key)
     if full is None:

@@ -65,6 +65,14 @@ class SpectreEncoderLayer(nn.Module):
         self.activation = activation  # resolved but never called, as in the reference (spectre.py:60-63)
 
     def forward(self, x):
+        return self._ff(self._mix(x))
+
+    def forward_cls(self, x):
+        """row 0 of forward(x), as (B, E): the mixer half over all tokens, the feed-forward half -- which works row by row -- at the CLS
+        rows only.  For the LAST layer of a stack whose consumer reads nothing but the CLS row (SpectreViT, reference spectre.py:198)."""
+        return self._ff(hip_ops.TakeClsFn.apply(self._mix(x)))
+
+    def _mix(self, x):
         x = hip_ops.cast(x, hip_ops.compute_dtype(x))
         if self.mixer == "fft":  # mixer + norm1 + residual as one autograd node (residual gradient folded into the FFT kernel)
             x = hip_ops.FNetResidualFn.apply(x, self.norm1.weight, self.norm1.bias)
@@ -72,6 +80,9 @@ class SpectreEncoderLayer(nn.Module):
             x = hip_ops.HaarResidualFn.apply(x, self.norm1.weight, self.norm1.bias)   # mixer + norm1 + residual as one row kernel each way
         else:
             x = hip_ops.add_layernorm(self.mix_layer(x), x, self.norm1.weight, self.norm1.bias, 0)
+        return x
+
+    def _ff(self, x):
         l1, l3 = self.linear1.local_head, self.linear3.local_head
         mult = 8 if x.dtype == torch.bfloat16 else 4
         if (l1[0].in_features % mult == 0 and l1[0].out_features % mult == 0):
@@ -110,22 +121,28 @@ class SpectreEncoder(nn.Module):
         reference spectre.py:198): same numbers, one (B, N, E) add and one gradient accumulation fewer per step."""
         src = hip_ops.cast(src, hip_ops.compute_dtype(src))
         output, src_cls = hip_ops.TapClsFn.apply(src)
-        for mod in self.layers:
-            output = mod(output)
-        if self.norm is not None:
-            output = self.norm(output)
+        output = self._stack_cls(output)
         return hip_ops.ClsAddFn.apply(output, src_cls)
 
+    def _stack_cls(self, output):
+        """the layer stack for a consumer of the CLS row: (B, 1, E) when the last layer's feed-forward half ran at the CLS rows only
+        (hip_ops.LAST_LAYER_CLS_ONLY), the full (B, N, E) otherwise"""
+        layers = list(self.layers)
+        cls_only = hip_ops.LAST_LAYER_CLS_ONLY and len(layers) > 0 and output.is_cuda
+        for mod in (layers[:-1] if cls_only else layers):
+            output = mod(output)
+        if cls_only:
+            output = layers[-1].forward_cls(output).unsqueeze(1)
+        if self.norm is not None:
+            output = self.norm(output)
+        return output
+
     def forward_cls_parts(self, src: torch.Tensor):
-        """forward_cls without the final CLS-row add: (stack output (B, N, E), CLS row of the stack input (B, E)) for a consumer
+        """forward_cls without the final CLS-row add: (stack output (B, N, E) or (B, 1, E), CLS row of the stack input (B, E)) for a consumer
         that folds the add into its own kernel (the class head, hip_ops.ClsHeadFn)."""
         src = hip_ops.cast(src, hip_ops.compute_dtype(src))
         output, src_cls = hip_ops.TapClsFn.apply(src)
-        for mod in self.layers:
-            output = mod(output)
-        if self.norm is not None:
-            output = self.norm(output)
-        return output, src_cls
+        return self._stack_cls(output), src_cls
 
 
 class SpectralPatchEmbed(nn.Module):
