@@ -48,6 +48,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed steps of the CPU baseline leg (bs = --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-every-row", action="store_true",
+                    help="skip the second graph-replayed measurement with the last layer's feed-forward half over every row (profiling runs)")
     return ap.parse_args(argv)
 
 
@@ -395,7 +397,7 @@ def main():
         # step with every row computed, as the reference does, is measured beside it.
         from spectre_vit import hip_ops
         rec["config"]["last_layer_feed_forward"] = "CLS rows only (exact; SPV_FULL_LAST_LAYER=1 for every row)" if hip_ops.LAST_LAYER_CLS_ONLY else "every row"
-        if hip_ops.LAST_LAYER_CLS_ONLY:
+        if hip_ops.LAST_LAYER_CLS_ONLY and not args.no_every_row:
             hip_ops.LAST_LAYER_CLS_ONLY = False
             try:
                 full = graph_replay(args, args.mixer, dev, max(5, min(args.steps, 20)), min(args.warmup, 5))

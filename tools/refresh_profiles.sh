@@ -13,7 +13,7 @@ for MIX in fft permut dwt_embed; do
   tail -c 300 "$OUT/${TAG}_${MIX}_bs512_bench.json" | head -c 10 > /dev/null
   echo "== stats $MIX"
   rm -rf /tmp/prof_$MIX
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$MIX -o p -- python3 "$ROOT/bench.py" --mixer $MIX --steps 20 --warmup 5 --no-roofline --no-cpu-baseline --variants none > "$OUT/${MIX}_stats.log" 2>&1 || echo "stats $MIX failed"
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$MIX -o p -- python3 "$ROOT/bench.py" --mixer $MIX --steps 20 --warmup 5 --no-roofline --no-cpu-baseline --no-every-row --variants none > "$OUT/${MIX}_stats.log" 2>&1 || echo "stats $MIX failed"
   F=$(find /tmp/prof_$MIX -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && cp "$F" "$OUT/${TAG}_${MIX}_bs512_kernel_stats.csv"
 done
