@@ -133,14 +133,34 @@ def test_dwt_step_at_bench_shapes(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_permut_layer_at_bench_shapes(dtype):
-    """one encoder layer with the HEAD mixer (MHPermutMix: gather + 8192 -> 512 SpectreLinear) at bs 128."""
-    cfg = dict(SMALL, num_encoders=1)
-    m, img, labels, sd = _setup(cfg, "permut", 128, 21)
-    ref = oracle_step("permut128", img, labels, sd, 1, 4, "permut")
-    before = census()
-    run_and_compare(m, img, labels, ref, dtype, "permut bs128")
-    took = {k: census()[k] - before[k] for k in before}
+    """one encoder layer with the HEAD mixer (MHPermutMix: gather + 8192 -> 512 SpectreLinear) at bs 128, every row computed."""
+    from spectre_vit import hip_ops
+    keep = hip_ops.LAST_LAYER_CLS_ONLY
+    hip_ops.LAST_LAYER_CLS_ONLY = False
+    try:
+        cfg = dict(SMALL, num_encoders=1)
+        m, img, labels, sd = _setup(cfg, "permut", 128, 21)
+        ref = oracle_step("permut128", img, labels, sd, 1, 4, "permut")
+        before = census()
+        run_and_compare(m, img, labels, ref, dtype, "permut bs128")
+        took = {k: census()[k] - before[k] for k in before}
+    finally:
+        hip_ops.LAST_LAYER_CLS_ONLY = keep
     assert took["gather_lds"] >= (1 if dtype == torch.bfloat16 else 0), took
+
+
+@pytest.mark.parametrize("layers", [1, 2])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_permut_last_layer_cls_rows_only(dtype, layers):
+    """The default form of the HEAD mixer's last layer: MHPermutMix's row 0 from ONE gathered row per image (MHPermutMix.forward_cls),
+    the feed-forward half at the CLS rows -- logits, loss and every gradient vs the float64 oracle of the full computation (one layer:
+    the CLS-only layer alone; two: behind a full layer whose input gradient it must deliver densely)."""
+    from spectre_vit import hip_ops
+    assert hip_ops.LAST_LAYER_CLS_ONLY
+    cfg = dict(SMALL, num_encoders=layers)
+    m, img, labels, sd = _setup(cfg, "permut", 128, 21 + layers)
+    ref = oracle_step(f"permut128x{layers}", img, labels, sd, layers, 4, "permut")
+    run_and_compare(m, img, labels, ref, dtype, f"permut bs128, {layers} layer(s), CLS-only last layer")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
