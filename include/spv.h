@@ -223,6 +223,15 @@ int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g, void* poo
                           int heads, int d, int dtype, void* stream);
 int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* dx, int batch, int heads, int d,
                           int dtype, void* stream);
+/* Token row 0 of the gathered matrix only (the last layer of a stack whose consumer reads the CLS row): g0[b][c] = +-x[b][idx[c]]
+ * for the first n = heads * embed entries of the forward table (reference layers.py:71-72: row t of the raw view is the chunk
+ * [t n, (t + 1) n) of the flattened (heads, d) gather), x0[b] = the sample's own row 0.  Backward: dx[b] = dx0[b] in row 0, zero
+ * elsewhere, + the n scattered values.  idx: the table of spv_permut_pack (its forward part comes first). */
+int spv_permut_row0_fwd(const void* x, const uint32_t* idx, void* g0, void* x0, int batch, int d, int n, int embed, int dtype,
+                        void* stream);
+int spv_permut_row0_bwd(const void* dg0, const void* dx0, const uint32_t* idx, void* dx, int batch, int d, int n, int embed,
+                        int dtype, void* stream);
+
 
 /* ---- FNet token mixer y = Re(fft2(x)) over (tokens, dim), un-normalised ------------------------------
  * spectre_vit/models/spectre_branch/spectre_branch.py:79, repl/orthogonal_permut.py:23-28 ('fft_bare',

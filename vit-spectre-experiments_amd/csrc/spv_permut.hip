@@ -550,3 +550,74 @@ extern "C" int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* 
     SPV_LAUNCH_CHECK("spv_permut_gather_bwd");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Token row 0 only (the last layer of a stack whose consumer reads the CLS row: hip_ops.LAST_LAYER_CLS_ONLY).  Row t of the gathered
+// matrix is the chunk [t n, (t + 1) n) of the flattened (heads, d) gather (n = heads * embed: the raw view of reference
+// layers.py:72), so row 0 is the first n entries of the forward table: g0[b][c] = +-x[b][idx[c]].  The same launch copies the
+// sample's own row 0 (the residual's CLS row).  Backward: dx[b][:] = dx0 in row 0, zero elsewhere, then += the n scattered values
+// (a permutation's entries are distinct: no atomics).
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void permut_row0_fwd_kernel(const T* __restrict__ x, const uint32_t* __restrict__ idx, T* __restrict__ g0,
+                                                              T* __restrict__ x0, int d, int n, int E) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const uint32_t w = idx[c];
+    const float v = io<T>::ld(x + (size_t)b * d + (w & 0x7fffffffu));
+    io<T>::st(g0 + (size_t)b * n + c, (w >> 31) ? -v : v);
+    if (c < E) x0[(size_t)b * E + c] = x[(size_t)b * d + c];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void permut_row0_init_kernel(const T* __restrict__ dx0, T* __restrict__ dx, int d, int E) {
+    // 8 elements (16 or 32 bytes) per thread; d and E are multiples of 8
+    const int b = blockIdx.y, p = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (p >= d) return;
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p < E ? dx0[(size_t)b * E + p + u] : T(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) dx[(size_t)b * d + p + u] = v[u];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void permut_row0_scatter_kernel(const T* __restrict__ dg0, const uint32_t* __restrict__ idx, T* __restrict__ dx,
+                                                                  int d, int n) {
+    const int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const uint32_t w = idx[c];
+    const float v = io<T>::ld(dg0 + (size_t)b * n + c);
+    T* dst = dx + (size_t)b * d + (w & 0x7fffffffu);
+    io<T>::st(dst, io<T>::ld(dst) + ((w >> 31) ? -v : v));
+}
+}  // namespace
+
+extern "C" int spv_permut_row0_fwd(const void* x, const uint32_t* idx, void* g0, void* x0, int batch, int d, int n, int embed, int dtype,
+                                   void* stream) {
+    SPV_CHECK(batch > 0 && d > 0 && n > 0 && n <= d && embed > 0 && embed <= d, "spv_permut_row0_fwd: batch=%d d=%d n=%d embed=%d", batch, d, n, embed);
+    SPV_CHECK(dtype == SPV_F32 || dtype == SPV_BF16, "spv_permut_row0_fwd: bad dtype %d", dtype);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(cdiv(n, 256), batch);
+    if (dtype == SPV_BF16)
+        hipLaunchKernelGGL(permut_row0_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, idx, (bf16_t*)g0, (bf16_t*)x0, d, n, embed);
+    else
+        hipLaunchKernelGGL(permut_row0_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, idx, (float*)g0, (float*)x0, d, n, embed);
+    SPV_LAUNCH_CHECK("spv_permut_row0_fwd");
+    return 0;
+}
+
+extern "C" int spv_permut_row0_bwd(const void* dg0, const void* dx0, const uint32_t* idx, void* dx, int batch, int d, int n, int embed,
+                                   int dtype, void* stream) {
+    SPV_CHECK(batch > 0 && d > 0 && n > 0 && n <= d && embed > 0 && embed <= d && d % 8 == 0 && embed % 8 == 0,
+              "spv_permut_row0_bwd: batch=%d d=%d n=%d embed=%d (d, embed multiples of 8)", batch, d, n, embed);
+    SPV_CHECK(dtype == SPV_F32 || dtype == SPV_BF16, "spv_permut_row0_bwd: bad dtype %d", dtype);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == SPV_BF16) {
+        hipLaunchKernelGGL(permut_row0_init_kernel<bf16_t>, dim3(cdiv(d / 8, 256), batch), dim3(256), 0, st, (const bf16_t*)dx0, (bf16_t*)dx, d, embed);
+        hipLaunchKernelGGL(permut_row0_scatter_kernel<bf16_t>, dim3(cdiv(n, 256), batch), dim3(256), 0, st, (const bf16_t*)dg0, idx, (bf16_t*)dx, d, n);
+    } else {
+        hipLaunchKernelGGL(permut_row0_init_kernel<float>, dim3(cdiv(d / 8, 256), batch), dim3(256), 0, st, (const float*)dx0, (float*)dx, d, embed);
+        hipLaunchKernelGGL(permut_row0_scatter_kernel<float>, dim3(cdiv(n, 256), batch), dim3(256), 0, st, (const float*)dg0, idx, (float*)dx, d, n);
+    }
+    SPV_LAUNCH_CHECK("spv_permut_row0_bwd");
+    return 0;
+}

@@ -48,6 +48,8 @@ SIGNATURES = {
     "spv_add_layernorm_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_add_layernorm_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "spv_permut_row0_fwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
+    "spv_permut_row0_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_table_words": [c_i, c_i],
     "spv_tail_bwd_parts": [c_i],
     "spv_haar_ln_supported": [c_i, c_i],

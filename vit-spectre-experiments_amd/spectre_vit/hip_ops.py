@@ -1157,6 +1157,34 @@ class TakeClsFn(torch.autograd.Function):
         return _cls_row_gradient(shape, dtype, g.device, g)
 
 
+class PermutClsFn(torch.autograd.Function):
+    """x (B, N, E) -> (token row 0 of the MHPermutMix gather (B, n), x[:, 0, :] (B, E)): the two things the LAST layer of a stack needs
+    of its input when the consumer reads the CLS row only (MHPermutMix.forward_cls).  Backward: ONE dense input gradient -- the CLS
+    row's own gradient in row 0, zero elsewhere, + the n scattered values -- instead of two (B, N, E) tensors for autograd to add."""
+
+    @staticmethod
+    def forward(ctx, x, table, n):
+        _require_gpu(x)
+        B, N, E = x.shape
+        xc = x.contiguous()
+        g0 = torch.empty((B, n), dtype=xc.dtype, device=xc.device)
+        x0 = torch.empty((B, E), dtype=xc.dtype, device=xc.device)
+        _native.call("spv_permut_row0_fwd", _p(xc), _p(table), _p(g0), _p(x0), B, N * E, n, E, _dt(xc), _stream())
+        ctx.table = table
+        ctx.meta = (B, N, E, n, xc.dtype)
+        return g0, x0
+
+    @staticmethod
+    def backward(ctx, dg0, dx0):
+        B, N, E, n, dtype = ctx.meta
+        dev = ctx.table.device
+        dg0 = torch.zeros((B, n), dtype=dtype, device=dev) if dg0 is None else dg0.to(dtype).contiguous()
+        dx0 = torch.zeros((B, E), dtype=dtype, device=dev) if dx0 is None else dx0.to(dtype).contiguous()
+        dx = torch.empty((B, N, E), dtype=dtype, device=dev)
+        _native.call("spv_permut_row0_bwd", _p(dg0), _p(dx0), _p(ctx.table), _p(dx), B, N * E, n, E, _DT[dtype], _stream())
+        return dx, None, None
+
+
 def _cls_row_gradient(shape, dtype, dev, rows):
     """The stack's output gradient when only the CLS rows carry one: a (B, N, E) tensor that is zero off row 0.  The buffer is kept
     across steps -- nothing ever writes its other rows (the consumers read it; TapClsFn adds in place to row 0 only) -- so a step

@@ -95,17 +95,13 @@ class MHPermutMix(nn.Module):
         return self.linear(g.view(B, self.token_dim, self.concat_dim))
 
     def forward_cls(self, x):
-        """row 0 of forward(x), as (B, out_channels).  Token row t of the gathered matrix is the chunk [t * concat_dim, (t + 1) *
-        concat_dim) of the flattened (heads, d) gather (the raw view of reference layers.py:72), so row 0 needs the first concat_dim
-        entries of the flattened permutation: 8192 of the 532 480 gathered values per image, one GEMM row instead of 65.  For the last
-        layer of a stack whose consumer reads the CLS row only (hip_ops.LAST_LAYER_CLS_ONLY).  The index pick itself is 16 KB per image:
-        torch's indexing kernels (and their autograd) do it; the SpectreLinear behind it is the same HIP node on B rows."""
-        B = x.shape[0]
+        """(row 0 of forward(x) as (B, out_channels), x[:, 0, :]).  Token row t of the gathered matrix is the chunk [t * concat_dim,
+        (t + 1) * concat_dim) of the flattened (heads, d) gather (the raw view of reference layers.py:72), so row 0 needs the first
+        concat_dim entries of the forward table: 8192 of the 532 480 gathered values per image, one GEMM row instead of 65.  For the
+        last layer of a stack whose consumer reads the CLS row only (hip_ops.LAST_LAYER_CLS_ONLY)."""
         x = hip_ops.cast(x, hip_ops.compute_dtype(x))
-        idx = self.perms.reshape(-1)[:self.concat_dim]
-        sg = self.signs.reshape(-1)[:self.concat_dim].to(x.dtype)
-        g0 = x.reshape(B, -1)[:, idx] * sg
-        return self.linear(g0)
+        g0, x0 = hip_ops.PermutClsFn.apply(x, self._table(), self.concat_dim)
+        return self.linear(g0), x0
 
 
 def _padded_linear(x, weight):

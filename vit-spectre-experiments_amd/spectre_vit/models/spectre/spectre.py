@@ -72,9 +72,8 @@ class SpectreEncoderLayer(nn.Module):
         rows only.  For the LAST layer of a stack whose consumer reads nothing but the CLS row (SpectreViT, reference spectre.py:198)."""
         if self.mixer == "permut" and self.mix_layer.concat_dim <= self.mix_layer.embed_dim * self.mix_layer.token_dim:
             # MHPermutMix is a gather + a row-wise SpectreLinear: its own row 0 needs one gathered row, not 65
-            x = hip_ops.cast(x, hip_ops.compute_dtype(x))
-            x1 = hip_ops.add_layernorm(self.mix_layer.forward_cls(x), hip_ops.TakeClsFn.apply(x), self.norm1.weight, self.norm1.bias, 0)
-            return self._ff(x1)
+            m0, x0 = self.mix_layer.forward_cls(hip_ops.cast(x, hip_ops.compute_dtype(x)))
+            return self._ff(hip_ops.add_layernorm(m0, x0, self.norm1.weight, self.norm1.bias, 0))
         return self._ff(hip_ops.TakeClsFn.apply(self._mix(x)))
 
     def _mix(self, x):
