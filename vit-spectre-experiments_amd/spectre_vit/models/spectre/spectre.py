@@ -74,6 +74,10 @@ class SpectreEncoderLayer(nn.Module):
             # MHPermutMix is a gather + a row-wise SpectreLinear: its own row 0 needs one gathered row, not 65
             m0, x0 = self.mix_layer.forward_cls(hip_ops.cast(x, hip_ops.compute_dtype(x)))
             return self._ff(hip_ops.add_layernorm(m0, x0, self.norm1.weight, self.norm1.bias, 0))
+        if self.mixer == "dwt_embed":
+            # the Haar transform along the embedding axis is row-wise too: the whole layer runs at the CLS rows
+            x0 = hip_ops.TakeClsFn.apply(hip_ops.cast(x, hip_ops.compute_dtype(x)))
+            return self._ff(self._mix(x0.unsqueeze(1)).squeeze(1))
         return self._ff(hip_ops.TakeClsFn.apply(self._mix(x)))
 
     def _mix(self, x):
