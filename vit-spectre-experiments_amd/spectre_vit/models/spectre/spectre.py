@@ -196,13 +196,16 @@ class SpectreViT(nn.Module):
 
     def _shadow_weights(self):
         """the encoder's nn.Linear weights whose bf16 (W, W^T) copies the GEMMs read (rebuilt every training forward)"""
+        cand = self.__dict__.get("_shadow_candidates")
+        if cand is None or cand[0] != len(self.encoder_blocks.layers):
+            # the module walk costs the host 0.1 ms per step (the eager, data-parallel path is host-bound): done once per stack
+            mods = [mod for layer in self.encoder_blocks.layers for mod in layer.modules() if isinstance(mod, SpectreLinear)]
+            cand = self.__dict__["_shadow_candidates"] = (len(self.encoder_blocks.layers), mods)
         ws = []
-        for layer in self.encoder_blocks.layers:
-            for mod in layer.modules():
-                if isinstance(mod, SpectreLinear):
-                    w = mod.local_head[0].weight
-                    if w.requires_grad and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
-                        ws.append(w)
+        for mod in cand[1]:
+            w = mod.local_head[0].weight   # (looked up every time: a caller may have replaced the parameter)
+            if w.requires_grad and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0:
+                ws.append(w)
         return ws
 
     def forward(self, x, return_features=False):
