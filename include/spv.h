@@ -255,6 +255,17 @@ int spv_fnet_ln_fwd(const void* x, void* prenorm, void* out, const float* gamma,
 int spv_fnet_ln_bwd(const void* dout, const void* prenorm, const float* mean, const float* rstd, const float* gamma, void* dx,
                     float* dgamma, float* dbeta, float* partials, const float* twiddle, int batch, int tokens, int dim, int dtype,
                     void* stream);
+
+/* Row 0 only of the same node, x1[:, 0, :] = LayerNorm1(Re(fft2(x))[0, :]) + x[:, 0, :] -- the last layer of a stack whose
+ * consumer reads the CLS row (reference spectre.py:66 + 198).  Token frequency 0 is the sum over tokens: one pass over the sample
+ * and ONE dim-point FFT.  out [batch, dim] (dtype), m0 [batch, dim] fp32 (the pre-norm row, kept for the backward), mean / rstd
+ * [batch].  Backward: g1 [batch, dim] -> dx [batch, tokens, dim] (every row the same spectrum, row 0 + g1), partials
+ * [batch][2][dim] = each sample's dgamma / dbeta contribution (summed by a fold job: spv_fold_multi / a riding fold). */
+int spv_fnet_cls_supported(int tokens, int dim, int dtype);
+int spv_fnet_cls_fwd(const void* x, const float* gamma, const float* beta, void* out, float* m0, float* mean, float* rstd, int batch,
+                     int tokens, int dim, int dtype, void* stream);
+int spv_fnet_cls_bwd(const void* g1, const float* m0, const float* mean, const float* rstd, const float* gamma, void* dx,
+                     float* partials, int batch, int tokens, int dim, int dtype, void* stream);
 int64_t spv_fnet_twiddle_floats(int tokens);
 int spv_fnet_make_twiddle(float* twiddle, int tokens, void* stream);
 

@@ -891,3 +891,45 @@ def test_gemm_pool_bwd_windows(ops, M, N, K, pw):
                  torch.cuda.current_stream().cuda_stream)
     ref = n64(A) @ n64(B).T + np.repeat(n64(D), pw, axis=1) / pw
     check(C, ref, 1.5e-2, f"pool_bwd pw={pw}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(6, 65, 512), (3, 17, 256), (2, 5, 1024)])
+def test_fnet_cls_row_matches_the_full_node(dtype, shape):
+    """FNetClsFn (row 0 of mixer + LayerNorm-1 + residual from ONE FFT of the token sum) against row 0 of the definition in float64:
+    output, input gradient (every token the same spectrum, row 0 + the residual's) and the LayerNorm parameter gradients."""
+    from spectre_vit import hip_ops
+    d = torch.device("cuda:0")
+    B, N, D = shape
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    x = torch.randn(B, N, D, generator=g)
+    w = 1.0 + 0.2 * torch.randn(D, generator=g)
+    b = 0.2 * torch.randn(D, generator=g)
+    go = torch.randn(B, D, generator=g)
+    # float64 definition (reference spectre.py:66 with the FFT mixer), row 0
+    x64 = x.double().requires_grad_(True)
+    w64, b64 = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    m = torch.fft.fft(torch.fft.fft(x64, dim=-1), dim=-2).real
+    ref = (torch.nn.functional.layer_norm(m, (D,), w64, b64, 1e-5) + x64)[:, 0, :]
+    ref.backward(go.double())
+    xd = x.to(d).to(dtype).requires_grad_(True)
+    wd, bd = w.to(d).requires_grad_(True), b.to(d).requires_grad_(True)
+    assert hip_ops.fnet_cls_ok(xd)
+    out = hip_ops.FNetClsFn.apply(xd, wd, bd)
+    out.backward(go.to(d).to(dtype))
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+
+    def rel(a, r):
+        return ((a.double().cpu() - r).norm() / r.norm()).item()
+    # the bf16 input is a rounded x: compare against the definition on the SAME rounded input
+    if dtype == torch.bfloat16:
+        x64b = x.to(dtype).double().requires_grad_(True)
+        w64b, b64b = w.double().requires_grad_(True), b.double().requires_grad_(True)
+        mb = torch.fft.fft(torch.fft.fft(x64b, dim=-1), dim=-2).real
+        refb = (torch.nn.functional.layer_norm(mb, (D,), w64b, b64b, 1e-5) + x64b)[:, 0, :]
+        refb.backward(go.to(dtype).double())
+        ref, x64, w64, b64 = refb, x64b, w64b, b64b
+    assert rel(out.detach(), ref.detach()) < tol
+    assert rel(xd.grad, x64.grad) < tol
+    assert rel(wd.grad, w64.grad) < tol and rel(bd.grad, b64.grad) < tol

@@ -1084,3 +1084,141 @@ extern "C" int spv_fnet_ln_bwd(const void* dout, const void* prenorm, const floa
     SPV_LAUNCH_CHECK("spv_fnet_ln_bwd(fold)");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Row 0 only of  x1 = LayerNorm1(Re(F_N x F_D)) + x  (the LAST layer of a stack whose consumer reads the CLS row: hip_ops.
+// LAST_LAYER_CLS_ONLY).  Token frequency 0 is the plain sum over tokens, so
+//   m0[j] = Re(F_N x F_D)[0, j] = sum_d s[d] cos(2 pi j d / D),  s[d] = sum_n x[n, d]  =  Re(FFT_D(s))[j]:
+// one pass over the sample (66 KB) and ONE D-point FFT instead of the 2-D transform; the backward is dx[n, :] = Re(FFT_D(dm0)) for
+// every n (+ the residual's gradient in row 0): one 66 KB write.  One workgroup of D / 2 threads per sample, thread t owns columns
+// 2t and 2t + 1; the FFT is a radix-2 decimation-in-time pass over a bit-reversed LDS image, fp32 throughout.
+namespace {
+template <int D> __device__ __forceinline__ int bitrev(int v) {
+    constexpr int LG = D == 256 ? 8 : D == 512 ? 9 : 10;
+    return (int)(__builtin_bitreverse32((unsigned)v) >> (32 - LG));
+}
+// in: re[] holds the real input in bit-reversed order, im[] zero; out: natural order.  tw: cos / sin of 2 pi k / D, k < D / 2
+template <int D> __device__ __forceinline__ void fft_real_lds(float* re, float* im, const float* twc, const float* tws, int t) {
+#pragma unroll 1
+    for (int len = 2; len <= D; len <<= 1) {
+        const int half = len >> 1, k = t & (half - 1), i0 = ((t / half) * len) + k, i1 = i0 + half;
+        const int ti = k * (D / len);
+        const float c = twc[ti], sn = -tws[ti];   // exp(-2 pi i k / len)
+        __syncthreads();
+        const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+        const float tr = br * c - bi * sn, tim = br * sn + bi * c;
+        re[i0] = ar + tr; im[i0] = ai + tim;
+        re[i1] = ar - tr; im[i1] = ai - tim;
+    }
+    __syncthreads();
+}
+template <int D> __device__ __forceinline__ float block_sum(float v, float* red, int t) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    float a = 0.0f;
+#pragma unroll
+    for (int w = 0; w < D / 128; ++w) a += red[w];
+    return a;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(D / 2) void fnet_cls_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             T* __restrict__ out, float* __restrict__ m0, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int N) {
+    __shared__ float re[D], im[D], twc[D / 2], tws[D / 2], red[8];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const T* xs = x + (size_t)b * N * D + 2 * t;
+    float s0 = 0.0f, s1 = 0.0f;
+    const float x00 = io<T>::ld(xs), x01 = io<T>::ld(xs + 1);
+#pragma unroll 5
+    for (int n = 0; n < N; ++n) {
+        s0 += io<T>::ld(xs + (size_t)n * D);
+        s1 += io<T>::ld(xs + (size_t)n * D + 1);
+    }
+    {
+        float sn, c;
+        sincospif(2.0f * (float)t / (float)D, &sn, &c);
+        twc[t] = c; tws[t] = sn;
+    }
+    re[bitrev<D>(2 * t)] = s0; re[bitrev<D>(2 * t + 1)] = s1;
+    im[2 * t] = 0.0f; im[2 * t + 1] = 0.0f;
+    __syncthreads();   // (hipcc hoists the loop's twiddle reads above the loop's own first barrier: the table must be complete here)
+    fft_real_lds<D>(re, im, twc, tws, t);
+    const float a0 = re[2 * t], a1 = re[2 * t + 1];
+    const float mu = block_sum<D>(a0 + a1, red, t) * (1.0f / D);
+    const float d0 = a0 - mu, d1 = a1 - mu;
+    const float var = block_sum<D>(d0 * d0 + d1 * d1, red, t) * (1.0f / D);
+    const float rs = rsqrtf(var + 1e-5f);
+    m0[(size_t)b * D + 2 * t] = a0; m0[(size_t)b * D + 2 * t + 1] = a1;
+    if (t == 0) { mean[b] = mu; rstd[b] = rs; }
+    io<T>::st(out + (size_t)b * D + 2 * t, d0 * rs * gamma[2 * t] + beta[2 * t] + x00);
+    io<T>::st(out + (size_t)b * D + 2 * t + 1, d1 * rs * gamma[2 * t + 1] + beta[2 * t + 1] + x01);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(D / 2) void fnet_cls_bwd_kernel(const T* __restrict__ g1, const float* __restrict__ m0, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ gamma, T* __restrict__ dx,
+                                                             float* __restrict__ partials, int N) {
+    __shared__ float re[D], im[D], twc[D / 2], tws[D / 2], red[8];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float mu = mean[b], rs = rstd[b];
+    const float g0 = io<T>::ld(g1 + (size_t)b * D + 2 * t), gq = io<T>::ld(g1 + (size_t)b * D + 2 * t + 1);
+    const float h0 = (m0[(size_t)b * D + 2 * t] - mu) * rs, h1 = (m0[(size_t)b * D + 2 * t + 1] - mu) * rs;
+    float* pp = partials + (size_t)b * 2 * D;   // [2][D]: dgamma, dbeta contributions of this sample (folded over the batch by a fold job)
+    pp[2 * t] = g0 * h0; pp[2 * t + 1] = gq * h1;
+    pp[D + 2 * t] = g0; pp[D + 2 * t + 1] = gq;
+    const float q0 = g0 * gamma[2 * t], q1 = gq * gamma[2 * t + 1];
+    const float sa = block_sum<D>(q0 + q1, red, t) * (1.0f / D);
+    const float sb = block_sum<D>(q0 * h0 + q1 * h1, red, t) * (1.0f / D);
+    const float e0 = rs * (q0 - sa - h0 * sb), e1 = rs * (q1 - sa - h1 * sb);
+    {
+        float sn, c;
+        sincospif(2.0f * (float)t / (float)D, &sn, &c);
+        twc[t] = c; tws[t] = sn;
+    }
+    re[bitrev<D>(2 * t)] = e0; re[bitrev<D>(2 * t + 1)] = e1;
+    im[2 * t] = 0.0f; im[2 * t + 1] = 0.0f;
+    __syncthreads();   // (hipcc hoists the loop's twiddle reads above the loop's own first barrier: the table must be complete here)
+    fft_real_lds<D>(re, im, twc, tws, t);
+    const float v0 = re[2 * t], v1 = re[2 * t + 1];
+    T* dst = dx + (size_t)b * N * D + 2 * t;
+    io<T>::st(dst, v0 + g0); io<T>::st(dst + 1, v1 + gq);   // row 0: + the residual's gradient
+    T w0, w1;
+    io<T>::st(&w0, v0); io<T>::st(&w1, v1);
+#pragma unroll 4
+    for (int n = 1; n < N; ++n) { dst[(size_t)n * D] = w0; dst[(size_t)n * D + 1] = w1; }
+}
+}  // namespace
+
+extern "C" int spv_fnet_cls_supported(int tokens, int dim, int dtype) {
+    static const bool off = getenv("SPV_FNET_NO_CLS") != nullptr;
+    return (!off && (dtype == SPV_BF16 || dtype == SPV_F32) && (dim == 256 || dim == 512 || dim == 1024) && tokens >= 1) ? 1 : 0;
+}
+
+extern "C" int spv_fnet_cls_fwd(const void* x, const float* gamma, const float* beta, void* out, float* m0, float* mean, float* rstd, int batch,
+                                int tokens, int dim, int dtype, void* stream) {
+    SPV_CHECK(spv_fnet_cls_supported(tokens, dim, dtype), "spv_fnet_cls_fwd: unsupported tokens=%d dim=%d dtype=%d", tokens, dim, dtype);
+    SPV_CHECK(batch > 0, "spv_fnet_cls_fwd: empty batch");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define SPV_CLS_F(TT, DD) hipLaunchKernelGGL((fnet_cls_fwd_kernel<TT, DD>), dim3(batch), dim3(DD / 2), 0, st, (const TT*)x, gamma, beta, (TT*)out, m0, mean, rstd, tokens)
+    if (dtype == SPV_BF16) { if (dim == 256) SPV_CLS_F(bf16_t, 256); else if (dim == 512) SPV_CLS_F(bf16_t, 512); else SPV_CLS_F(bf16_t, 1024); }
+    else { if (dim == 256) SPV_CLS_F(float, 256); else if (dim == 512) SPV_CLS_F(float, 512); else SPV_CLS_F(float, 1024); }
+#undef SPV_CLS_F
+    SPV_LAUNCH_CHECK("spv_fnet_cls_fwd");
+    return 0;
+}
+
+extern "C" int spv_fnet_cls_bwd(const void* g1, const float* m0, const float* mean, const float* rstd, const float* gamma, void* dx,
+                                float* partials, int batch, int tokens, int dim, int dtype, void* stream) {
+    SPV_CHECK(spv_fnet_cls_supported(tokens, dim, dtype), "spv_fnet_cls_bwd: unsupported tokens=%d dim=%d dtype=%d", tokens, dim, dtype);
+    SPV_CHECK(batch > 0, "spv_fnet_cls_bwd: empty batch");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define SPV_CLS_B(TT, DD) hipLaunchKernelGGL((fnet_cls_bwd_kernel<TT, DD>), dim3(batch), dim3(DD / 2), 0, st, (const TT*)g1, m0, mean, rstd, gamma, (TT*)dx, partials, tokens)
+    if (dtype == SPV_BF16) { if (dim == 256) SPV_CLS_B(bf16_t, 256); else if (dim == 512) SPV_CLS_B(bf16_t, 512); else SPV_CLS_B(bf16_t, 1024); }
+    else { if (dim == 256) SPV_CLS_B(float, 256); else if (dim == 512) SPV_CLS_B(float, 512); else SPV_CLS_B(float, 1024); }
+#undef SPV_CLS_B
+    SPV_LAUNCH_CHECK("spv_fnet_cls_bwd");
+    return 0;
+}

@@ -1557,6 +1557,48 @@ class FNetResidualFn(torch.autograd.Function):
         return dx, dn1w, dn1b
 
 
+def fnet_cls_ok(x):
+    """row 0 of the FFT mixer + LayerNorm-1 + residual can come from the one-FFT kernels (spv_fnet_cls_fwd / _bwd)"""
+    return x.is_cuda and x.dim() == 3 and x.dtype in _DT and bool(_native.call("spv_fnet_cls_supported", x.shape[1], x.shape[2], _dt(x)))
+
+
+class FNetClsFn(torch.autograd.Function):
+    """x (B, N, D) -> (LayerNorm1(Re(fft2(x))) + x)[:, 0, :] as (B, D): what the LAST layer of a stack needs of FNetResidualFn when the
+    consumer reads the CLS row only.  Token frequency 0 is the sum over tokens, so the row is ONE D-point FFT of the token sum
+    (spv_fnet_cls_fwd: one pass over x); the backward hands every token the same spectrum (+ the residual's gradient in row 0)."""
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b):
+        _require_gpu(x)
+        B, N, D = x.shape
+        xc = x.contiguous()
+        dev = xc.device
+        out = torch.empty((B, D), dtype=xc.dtype, device=dev)
+        m0 = torch.empty((B, D), dtype=torch.float32, device=dev)
+        mean = torch.empty((B,), dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        _native.call("spv_fnet_cls_fwd", _p(xc), _p(n1w), _p(n1b), _p(out), _p(m0), _p(mean), _p(rstd), B, N, D, _dt(xc), _stream())
+        ctx.saved = (m0, mean, rstd, n1w, (_sink(n1w), _sink(n1b)))
+        ctx.meta = (B, N, D, xc.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        m0, mean, rstd, n1w, sinks = ctx.saved
+        B, N, D, dtype = ctx.meta
+        dev = m0.device
+        g = g.to(dtype).contiguous()
+        dx = torch.empty((B, N, D), dtype=dtype, device=dev)
+        dn1w = _grad_buf(sinks[0], (D,), dev)
+        dn1b = _grad_buf(sinks[1], (D,), dev)
+        partials = torch.empty((B * 2 * D,), dtype=torch.float32, device=dev)
+        _native.call("spv_fnet_cls_bwd", _p(g), _p(m0), _p(mean), _p(rstd), _p(n1w), _p(dx), _p(partials), B, N, D, _DT[dtype], _stream())
+        if not _hold_fold(partials, (dn1w, dn1b), sinks, B, D):   # the batch sums of dgamma / dbeta: with the next reduce, or now
+            arr = _fold_array([(partials, (dn1w, dn1b), B, D)])
+            _native.call("spv_fold_multi", ctypes.addressof(arr), 1, _stream())
+        return dx, dn1w, dn1b
+
+
 class HaarResidualFn(torch.autograd.Function):
     """x1 = LayerNorm1(haar(x)) + x, one-level Haar DWT along the embedding axis (reference spectre.py:66 with the 'dwt_embed' mixer of
     BASELINE config 3): one row kernel each way (spv_haar_ln_fwd / _bwd; the transform is lane-local, nothing of the mixer is stored)."""

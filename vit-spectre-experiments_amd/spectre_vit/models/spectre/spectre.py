@@ -74,6 +74,11 @@ class SpectreEncoderLayer(nn.Module):
             # MHPermutMix is a gather + a row-wise SpectreLinear: its own row 0 needs one gathered row, not 65
             m0, x0 = self.mix_layer.forward_cls(hip_ops.cast(x, hip_ops.compute_dtype(x)))
             return self._ff(hip_ops.add_layernorm(m0, x0, self.norm1.weight, self.norm1.bias, 0))
+        if self.mixer == "fft":
+            xc = hip_ops.cast(x, hip_ops.compute_dtype(x))
+            if hip_ops.fnet_cls_ok(xc):
+                # row 0 of Re(fft2(x)) is one FFT of the token sum: the mixer half as one pass over x, its backward one write
+                return self._ff(hip_ops.FNetClsFn.apply(xc, self.norm1.weight, self.norm1.bias))
         if self.mixer == "dwt_embed":
             # the Haar transform along the embedding axis is row-wise too: the whole layer runs at the CLS rows
             x0 = hip_ops.TakeClsFn.apply(hip_ops.cast(x, hip_ops.compute_dtype(x)))
