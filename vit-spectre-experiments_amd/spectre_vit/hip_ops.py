@@ -443,10 +443,10 @@ def _flush_held_wgrads():
     """the weight gradients held back during this backward pass: one launch (+ one reduce that carries their folds and the folds held
     so far) per group of up to eight with the same row count"""
     while _held_wgrads:
-        rows = _held_wgrads[0][3]
+        rows = max(w[3] for w in _held_wgrads)   # the long reductions first: a small batch (the CLS-only last layer's) fills their drain
         group = [w for w in _held_wgrads if w[3] == rows][:WGRAD_BATCH]
-        for w in group:
-            _held_wgrads.remove(w)
+        taken = {id(w) for w in group}
+        _held_wgrads[:] = [w for w in _held_wgrads if id(w) not in taken]   # (by identity: the tuples hold tensors)
         probs = (_native.TnProblem * len(group))()
         tiles = floats = 0
         folds = []
