@@ -1130,13 +1130,46 @@ __global__ __launch_bounds__(D / 2) void fnet_cls_fwd_kernel(const T* __restrict
     __shared__ float re[D], im[D], twc[D / 2], tws[D / 2], red[8];
     const int b = blockIdx.x, t = threadIdx.x;
     const T* xs = x + (size_t)b * N * D + 2 * t;
-    float s0 = 0.0f, s1 = 0.0f;
     const float x00 = io<T>::ld(xs), x01 = io<T>::ld(xs + 1);
-#pragma unroll 5
-    for (int n = 0; n < N; ++n) {
-        s0 += io<T>::ld(xs + (size_t)n * D);
-        s1 += io<T>::ld(xs + (size_t)n * D + 1);
+    // token sum with 16-byte loads: EPV columns per lane, RG row groups of D / EPV lanes; partial sums joined through LDS (im[] and
+    // re[] are free until the FFT image is written)
+    constexpr int EPV = 16 / (int)sizeof(T), LPR = D / EPV, RG = (D / 2) / LPR;
+    {
+        const int rg = t / LPR, c0 = (t % LPR) * EPV;
+        float acc[EPV];
+#pragma unroll
+        for (int u = 0; u < EPV; ++u) acc[u] = 0.0f;
+        const T* xr = x + (size_t)b * N * D + c0;
+#pragma unroll 4
+        for (int n = rg; n < N; n += RG) {
+            if constexpr (sizeof(T) == 2) {
+                const uint4 q = *reinterpret_cast<const uint4*>(xr + (size_t)n * D);
+                acc[0] += __uint_as_float(q.x << 16); acc[1] += __uint_as_float(q.x & 0xffff0000u);
+                acc[2] += __uint_as_float(q.y << 16); acc[3] += __uint_as_float(q.y & 0xffff0000u);
+                acc[4] += __uint_as_float(q.z << 16); acc[5] += __uint_as_float(q.z & 0xffff0000u);
+                acc[6] += __uint_as_float(q.w << 16); acc[7] += __uint_as_float(q.w & 0xffff0000u);
+            } else {
+                const float4 q = *reinterpret_cast<const float4*>(xr + (size_t)n * D);
+                acc[0] += q.x; acc[1] += q.y; acc[2] += q.z; acc[3] += q.w;
+            }
+        }
+        float* part = rg < 1 ? re : (rg < 2 ? im : nullptr);
+        static_assert(RG <= 4, "row groups");
+        // RG = 2 (fp32): groups in re, im.  RG = 4 (bf16): groups 0, 1 in re / im, groups 2, 3 added in a second round
+        if (RG == 2 || rg < 2) {
+#pragma unroll
+            for (int u = 0; u < EPV; ++u) part[c0 + u] = acc[u];
+        }
+        __syncthreads();
+        if (RG == 4 && rg >= 2) {
+            float* p2 = rg == 2 ? re : im;
+#pragma unroll
+            for (int u = 0; u < EPV; ++u) p2[c0 + u] += acc[u];
+        }
+        __syncthreads();
     }
+    const float s0 = re[2 * t] + im[2 * t], s1 = re[2 * t + 1] + im[2 * t + 1];
+    __syncthreads();
     {
         float sn, c;
         sincospif(2.0f * (float)t / (float)D, &sn, &c);
@@ -1182,13 +1215,35 @@ __global__ __launch_bounds__(D / 2) void fnet_cls_bwd_kernel(const T* __restrict
     im[2 * t] = 0.0f; im[2 * t + 1] = 0.0f;
     __syncthreads();   // (hipcc hoists the loop's twiddle reads above the loop's own first barrier: the table must be complete here)
     fft_real_lds<D>(re, im, twc, tws, t);
-    const float v0 = re[2 * t], v1 = re[2 * t + 1];
-    T* dst = dx + (size_t)b * N * D + 2 * t;
-    io<T>::st(dst, v0 + g0); io<T>::st(dst + 1, v1 + gq);   // row 0: + the residual's gradient
-    T w0, w1;
-    io<T>::st(&w0, v0); io<T>::st(&w1, v1);
+    // every token row gets the same spectrum (row 0 + the residual's gradient): 16-byte stores, EPV columns per lane, RG row groups
+    constexpr int EPV = 16 / (int)sizeof(T), LPR = D / EPV, RG = (D / 2) / LPR;
+    const int rg = t / LPR, c0 = (t % LPR) * EPV;
+    float v[EPV];
+#pragma unroll
+    for (int u = 0; u < EPV; ++u) v[u] = re[c0 + u];
+    T* drow = dx + (size_t)b * N * D + c0;
+    if (rg == 0) {
+        float r0[EPV];
+#pragma unroll
+        for (int u = 0; u < EPV; ++u) r0[u] = v[u] + io<T>::ld(g1 + (size_t)b * D + c0 + u);
+        if constexpr (sizeof(T) == 2) {
+            uint4 q;
+            q.x = pack_bf16x2(r0[0], r0[1]); q.y = pack_bf16x2(r0[2], r0[3]); q.z = pack_bf16x2(r0[4], r0[5]); q.w = pack_bf16x2(r0[6], r0[7]);
+            *reinterpret_cast<uint4*>(drow) = q;
+        } else {
+            *reinterpret_cast<float4*>(drow) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        uint4 q;
+        q.x = pack_bf16x2(v[0], v[1]); q.y = pack_bf16x2(v[2], v[3]); q.z = pack_bf16x2(v[4], v[5]); q.w = pack_bf16x2(v[6], v[7]);
 #pragma unroll 4
-    for (int n = 1; n < N; ++n) { dst[(size_t)n * D] = w0; dst[(size_t)n * D + 1] = w1; }
+        for (int n = rg == 0 ? RG : rg; n < N; n += RG) *reinterpret_cast<uint4*>(drow + (size_t)n * D) = q;
+    } else {
+        const float4 q = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll 4
+        for (int n = rg == 0 ? RG : rg; n < N; n += RG) *reinterpret_cast<float4*>(drow + (size_t)n * D) = q;
+    }
 }
 }  // namespace
 
