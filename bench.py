@@ -396,7 +396,11 @@ def main():
         # logits, loss and gradients (tests/test_gpu_bench_shapes.py checks both forms against the oracle).  The same graph-replayed
         # step with every row computed, as the reference does, is measured beside it.
         from spectre_vit import hip_ops
-        rec["config"]["last_layer_feed_forward"] = "CLS rows only (exact; SPV_FULL_LAST_LAYER=1 for every row)" if hip_ops.LAST_LAYER_CLS_ONLY else "every row"
+        rec["config"]["last_layer_feed_forward"] = ("CLS rows only -- exact dead-row elimination: the model reads only the CLS row of the stack's output (reference spectre.py:198), so "
+                                                  "the last layer's row-wise half (and its mixer's row 0) is computed for that row alone; logits, loss and EVERY parameter "
+                                                  "gradient are those of the every-row computation (tests/test_gpu_bench_shapes.py runs both forms against the oracle); "
+                                                  "the every-row step is timed beside it under \"every_row_of_last_layer\" (SPV_FULL_LAST_LAYER=1 selects it)"
+                                                  if hip_ops.LAST_LAYER_CLS_ONLY else "every row")
         if hip_ops.LAST_LAYER_CLS_ONLY and not args.no_every_row:
             hip_ops.LAST_LAYER_CLS_ONLY = False
             try:
