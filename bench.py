@@ -2,11 +2,12 @@
 """Headline benchmark: images/sec of the Spectre-ViT-Small training step (CIFAR-100-shaped synthetic input,
 bs 512 per GPU, bf16) on N MI355X -- BASELINE.json's metric.  One JSON line on stdout (rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mixer fft|permut|dwt_embed|dwt_token] [--graph]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mixer fft|permut|dwt_embed|dwt_token] [--eager] [--dp-sequence]
 
 A step = forward + CrossEntropy + backward + (gradient all-reduce) + AdamW on one batch resident in HBM
-(reference loop: spectre_vit/repl/train.py:216-238).  N > 1: one rank per GPU, RCCL all-reduce of the gradients overlapped
-with backward; weak scaling (512 images per GPU).  ``python bench.py --gpus N`` starts its own ranks (a child
+(reference loop: spectre_vit/repl/train.py:216-238).  N > 1: one rank per GPU; a rank replays two HIP graphs around ONE RCCL
+all-reduce of its flat gradient buffer (spectre_vit.graph.GraphedDPStep; the HEAD mixer's 80 MB: eager, bucket all-reduces
+overlapped with backward); weak scaling (512 images per GPU).  ``python bench.py --gpus N`` starts its own ranks (a child
 ``torch.distributed.run`` spawned before this process touches the GPU); under an external ``torch.distributed.run`` (WORLD_SIZE
 set) it is one of the ranks.
 """
@@ -48,6 +49,12 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed steps of the CPU baseline leg (bs = --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dp-sequence", action="store_true",
+                    help="one GPU: the headline is the launch sequence of a data-parallel rank (graph A -> all-reduce in a one-rank RCCL "
+                         "group -> graph B) instead of the single graph")
+    ap.add_argument("--dp-graph", action="store_true", help="N GPUs, permut mixer: use the two-graph rank step as well (default: eager, overlapped)")
+    ap.add_argument("--no-dp-sequence", action="store_true", help="skip the dp_sequence leg of the single-GPU line")
+    ap.add_argument("--no-script-leg", action="store_true", help="skip the as_script leg (the reference loop verbatim) of the single-GPU line")
     ap.add_argument("--no-every-row", action="store_true",
                     help="skip the second graph-replayed measurement with the last layer's feed-forward half over every row (profiling runs)")
     return ap.parse_args(argv)
@@ -144,12 +151,19 @@ def attach_pmc_traffic(roof, mixer):
 
 
 class Job:
-    """model + optimizer + resident batch for one mixer; step() is the measured unit."""
+    """model + optimizer + resident batch for one mixer; step() is the measured unit.
 
-    def __init__(self, args, mixer, dev, rank, stand_in=False):
+    launch = "graph"     one HIP graph per step (spectre_vit.graph.GraphedTrainStep): the single-GPU headline
+             "dp_graph"  a data-parallel rank: graph A (forward + loss + backward) -> ONE all-reduce of the flat gradient buffer ->
+                         graph B (AdamW) (spectre_vit.graph.GraphedDPStep)
+             "eager"     every kernel launched by the host; gradients exchanged bucket by bucket, overlapped with the backward
+    eager_step() runs the SAME launch sequence as step() with the host issuing every launch (the roofline pass brackets it)."""
+
+    def __init__(self, args, mixer, dev, rank, launch="eager", stand_in=False, force_collective=False):
         import torch
         from spectre_vit.dp import GradReducer, broadcast_module
         self.torch = torch
+        self.launch = launch
         torch.manual_seed(42)
         if stand_in:  # CPU rehearsal of the launcher / collectives only (no GPU in this process): a small stock model
             model = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(3 * 32 * 32, 64), torch.nn.GELU(), torch.nn.Linear(64, 100))
@@ -167,25 +181,43 @@ class Job:
         self.img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
         labels = torch.randint(0, 100, (args.batch,), generator=g).to(torch.uint8).to(dev)  # uint8 as train.py:218
         self.labels = labels.long()
+        self.use_bf16 = args.dtype == "bf16" and not stand_in
+        self.dev = dev
+        self.param_bytes = sum(p.numel() for p in model.parameters()) * 4
+        self.timer = None
+        self.gstep = None
+        if stand_in:
+            self.crit = torch.nn.CrossEntropyLoss()
+        else:  # nn.CrossEntropyLoss() semantics on one launch each way (spectre_vit/loss.py; parity-tested against torch's)
+            from spectre_vit.loss import CrossEntropyLoss
+            self.crit = CrossEntropyLoss()
+        if launch in ("graph", "dp_graph"):
+            from spectre_vit.graph import GraphedDPStep, GraphedTrainStep
+            from spectre_vit.optim import FusedAdamW
+            self.opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, capturable=True, static_grads=True)
+            cls = GraphedDPStep if launch == "dp_graph" else GraphedTrainStep
+            self.gstep = cls(model, self.opt, self.crit, self.img, self.labels, autocast_dtype=torch.bfloat16 if self.use_bf16 else None,
+                             force_collective=force_collective)
+            self.reducer = self.gstep.reducer
+            return
         self.reducer = GradReducer(model, always=not stand_in)  # fixed gradient addresses (one-launch optimizer's pointer table)
         if stand_in or os.environ.get("SPV_TORCH_ADAMW") == "1":  # A/B aid: torch's own fused AdamW
             self.opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, fused=not stand_in)
         else:  # the same update rule on one launch (spectre_vit/optim.py; parity-tested against torch.optim.AdamW)
             from spectre_vit.optim import FusedAdamW
             self.opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, static_grads=True)
-        if stand_in:
-            self.crit = torch.nn.CrossEntropyLoss()
-        else:  # nn.CrossEntropyLoss() semantics on one launch each way (spectre_vit/loss.py; parity-tested against torch's)
-            from spectre_vit.loss import CrossEntropyLoss
-            self.crit = CrossEntropyLoss()
-        self.use_bf16 = args.dtype == "bf16" and not stand_in
         self.one = torch.ones((), dtype=torch.float32, device=dev)
-        self.dev = dev
-        self.param_bytes = sum(p.numel() for p in model.parameters()) * 4
-        self.timer = None
 
     def step(self):
+        if self.gstep is not None:
+            return self.gstep()
+        return self.eager_step()
+
+    def eager_step(self):
         torch = self.torch
+        if self.gstep is not None:   # the graph's own launch sequence (held / batched weight gradients included), issued by the host
+            with self.gstep._hold():
+                return self.gstep._eager_step()[0]
         self.reducer.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.use_bf16):
             out = self.model(self.img)
@@ -198,46 +230,95 @@ class Job:
             self.opt.step()  # (FusedAdamW's launch is bracketed by the C-ABI hook like every other kernel)
         return loss
 
+    def close(self):
+        if self.gstep is not None:
+            self.gstep.close()
+            self.gstep = None
 
-def timed_region(job, sync, steps, warmup):
+
+def timed_region(job, sync, steps, warmup, eager=False):
+    fn = job.eager_step if eager else job.step
     for _ in range(warmup):
-        job.step()
+        fn()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = job.step()
+        loss = fn()
     sync()
     return time.perf_counter() - t0, loss
 
 
-def graph_replay(args, mixer, dev, steps, warmup):
-    """The same step captured once in a HIP graph and replayed (single GPU; spectre_vit.graph.GraphedTrainStep): dropout as
-    configured -- a device-side seed word advanced inside the graph gives every replay fresh masks -- and the optimizer step inside."""
+def side_leg(args, mixer, dev, sync, launch, steps, warmup, force_collective=False):
+    """another configuration timed in the same process, in the SAME launch mode as the headline unless said otherwise"""
     import torch
-    from spectre_vit.graph import GraphedTrainStep
+    job = Job(args, mixer, dev, 0, launch=launch, force_collective=force_collective)
+    try:
+        el, loss = timed_region(job, sync, steps, warmup)
+        out = dict(value=round(args.batch * steps / el, 1), unit="images/sec", ms_per_step=round(el / steps * 1e3, 3), steps=steps,
+                   launch=launch, final_loss=round(float(loss.item()), 4))
+    finally:
+        job.close()
+        del job
+        torch.cuda.empty_cache()
+    return out
+
+
+def script_leg(args, mixer, dev, steps, warmup):
+    """The reference script's own loop on the mirror package, verbatim (spectre_vit/repl/train.py:216-238): fp16 autocast (served by the
+    bf16 kernels), GradScaler("cuda"), torch.optim.AdamW, zero_grad(set_to_none=True), loss.item() every step -- no gradient sinks,
+    no held weight gradients, no graph: what a user gets who changes nothing but the import path."""
+    import torch
+    import warnings
     from spectre_vit.models.spectre.spectre import SpectreViT
-    from spectre_vit.optim import FusedAdamW
     torch.manual_seed(42)
     model = SpectreViT(**SMALL, mixer=mixer).to(dev).train()
     g = torch.Generator(device="cpu").manual_seed(1234)
     img = torch.randn(args.batch, 3, 32, 32, generator=g).to(dev)
-    labels = torch.randint(0, 100, (args.batch,), generator=g).to(dev)
-    opt = FusedAdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, capturable=True, static_grads=True)
-    from spectre_vit.loss import CrossEntropyLoss
-    step = GraphedTrainStep(model, opt, CrossEntropyLoss(), img, labels,
-                            autocast_dtype=torch.bfloat16 if args.dtype == "bf16" else None)
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    out = dict(graph_ms_per_step=round(ms, 3), images_per_sec=round(args.batch / ms * 1e3, 1), final_loss=round(float(loss.item()), 4),
-               dropout=SMALL["dropout"], optimizer="spectre_vit.optim.FusedAdamW(capturable=True)")
-    step.close()
-    return out
+    label = torch.randint(0, 100, (args.batch,), generator=g).type(torch.uint8).to(dev)
+    criterion = torch.nn.CrossEntropyLoss()
+    optimizer = torch.optim.AdamW(model.parameters(), betas=(0.9, 0.999), lr=1e-3, weight_decay=0.01)
+    scaler = torch.amp.GradScaler("cuda")
+
+    def one():
+        with torch.autocast(device_type="cuda", dtype=torch.float16):
+            y_pred = model(img)
+        loss = criterion(y_pred, label)
+        optimizer.zero_grad(set_to_none=True)
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+        return loss.item()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = one()
+        torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    del model, optimizer
+    torch.cuda.empty_cache()
+    return dict(value=round(args.batch * steps / el, 1), unit="images/sec", ms_per_step=round(el / steps * 1e3, 3), steps=steps,
+                launch="the reference loop verbatim (train.py:216-238): fp16 autocast -> bf16 kernels, GradScaler, torch.optim.AdamW, "
+                       "zero_grad(set_to_none=True), loss.item() per step; eager, no sinks, no batching",
+                final_loss=round(float(last), 4))
+
+
+def one_rank_group(dev):
+    """a one-rank RCCL process group in this process (single-GPU --dp-sequence leg: the collective call of a rank is issued for real)"""
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return True
+    try:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+        return True
+    except Exception as exc:  # no RCCL in this environment: the leg still runs the two graphs, with the collective skipped
+        sys.stderr.write(f"bench.py: one-rank RCCL group unavailable ({exc}); dp_sequence runs without the collective call\n")
+        return False
 
 
 def main():
@@ -247,6 +328,7 @@ def main():
     if args.gpus > 1 and world_env is None:
         sys.exit(self_launch(args, argv))  # before torch / HIP are touched in this process
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL on this driver), also under an external launcher
     import torch
     import torch.distributed as dist
 
@@ -267,6 +349,14 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    # launch mode of the headline.  One GPU: the step replayed from one HIP graph.  N GPUs: a rank replays two graphs around one
+    # all-reduce (FFT / DWT models: 13 MB of gradients; the exposed collective costs less than the eager path's host time); the HEAD
+    # mixer's 80 MB keep the eager step whose bucket all-reduces overlap the backward.
+    graphable = args.model == "spectre" and not stand_in and not args.eager
+    if world > 1 or args.dp_sequence:
+        launch = "dp_graph" if graphable and (args.mixer != "permut" or args.dp_graph) else "eager"
+    else:
+        launch = "graph" if graphable else "eager"
     backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -274,11 +364,16 @@ def main():
             backend = "gloo"
             dist.init_process_group("gloo")
         else:
-            # the layer GEMMs leave 16 CUs to RCCL (spectre_vit.dp.RESERVED_CUS); keep RCCL inside them.  One step exchanges 80 MB
-            # of fp32 gradients, which 16 channels move well inside the backward.  An explicit NCCL_MAX_NCHANNELS wins.
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
+            if launch == "eager":
+                # the layer GEMMs leave 16 CUs to RCCL (spectre_vit.dp.RESERVED_CUS); keep RCCL inside them.  One step exchanges
+                # 80 MB of fp32 gradients, which 16 channels move well inside the backward.  An explicit NCCL_MAX_NCHANNELS wins.
+                os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
             backend = "nccl"
             dist.init_process_group("nccl", device_id=dev)
+    force_collective = False
+    if world == 1 and args.dp_sequence and launch == "dp_graph":
+        force_collective = one_rank_group(dev)
+        backend = "nccl (one-rank group)" if force_collective else None
     if args.model == "vit" or stand_in:
         args.no_cpu_baseline = True  # the CPU leg times the Spectre port
     if stand_in:
@@ -292,32 +387,45 @@ def main():
         if not stand_in:
             torch.cuda.synchronize()
 
-    job = Job(args, args.mixer, dev, rank, stand_in)
+    job = Job(args, args.mixer, dev, rank, launch=launch, stand_in=stand_in, force_collective=force_collective)
     elapsed, loss = timed_region(job, sync, args.steps, args.warmup)
-    # roofline pass: the same step, same process, right after the timed region, with HIP events recorded on the launch
-    # stream around EVERY C-ABI launch and the optimizer.  Kept out of the headline timing because the ~100 event pairs per
-    # step perturb it.  Every rank runs these steps (each one contains the gradient all-reduce: a rank that skipped them
-    # would leave the others waiting in the collective); only rank 0 records events.
+    final_loss = float(loss.item())
+    # roofline pass: the SAME launch sequence as the timed region (in the graph modes: the captured sequence issued by the host, with the
+    # layer weight gradients held and batched exactly as in the graph), same process, right after it, with HIP events recorded on the
+    # launch stream around EVERY C-ABI launch.  Kept out of the headline timing because ~70 event pairs per step perturb it.  Every rank
+    # runs these steps (each one contains the gradient exchange); only rank 0 records events.
     timer = None
     rsteps = min(args.steps, 10)
+    eager_fig = None
     if not args.no_roofline:
         from spectre_vit import hip_ops
+        hip_ops.TIME_HELD = launch != "eager"
         if rank == 0:
             timer = hip_ops.KernelTimer()
             hip_ops.set_kernel_timer(timer)
             job.timer = timer
         for _ in range(rsteps):
-            job.step()
+            job.eager_step()
         torch.cuda.synchronize()
         hip_ops.set_kernel_timer(None)
+        hip_ops.TIME_HELD = False
         job.timer = None
+    if launch != "eager" and world == 1:
+        # the same launch sequence with the host issuing every launch: what the graph removes
+        esteps = max(5, min(args.steps, 20))
+        eel, eloss = timed_region(job, sync, esteps, 2, eager=True)
+        eager_fig = {"value": round(args.batch * esteps / eel, 1), "ms_per_step": round(eel / esteps * 1e3, 3), "steps": esteps,
+                     "final_loss": round(float(eloss.item()), 4)}
     if world > 1:
         dist.barrier()
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
-    final_loss = float(loss.item())
 
+    launch_text = {"graph": "one HIP graph per step (spectre_vit.graph.GraphedTrainStep); the same launch sequence issued by the host under \"eager\"",
+                   "dp_graph": "per rank: HIP graph A (forward + loss + backward, batched weight gradients) -> one all-reduce of the flat "
+                               "gradient buffer -> HIP graph B (AdamW) (spectre_vit.graph.GraphedDPStep)",
+                   "eager": "every launch issued by the host; gradient buckets all-reduced during the backward pass (spectre_vit.dp.GradReducer)"}[launch]
     rec = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -345,11 +453,17 @@ def main():
                                          if stand_in else
                                          "all ranks on one device over gloo: control-flow check, not a measurement")} if rehearsal else {}),
                        "mixer": args.mixer if args.model == "spectre" else "attention", "global_batch": args.batch * world,
-                       "parallelism": f"dp{world}"},
-            "rccl_ranks": world if backend == "nccl" else 0,
+                       "parallelism": f"dp{world}", "launch": launch_text},
+            "rccl_ranks": world if backend == "nccl" else (1 if force_collective else 0),
             "backend": backend or "none (single process)",
             "final_loss": round(final_loss, 4),
         }
+        if launch != "eager" and not stand_in:
+            rec["gradient_exchange"] = ({"bytes": int(job.reducer.flat.numel() * 4), "calls_per_step": 1,
+                                         "form": "one all-reduce (mean) of the flat fp32 gradient buffer between graph A and graph B"}
+                                        if launch == "dp_graph" else None)
+        if eager_fig is not None:
+            rec["eager"] = eager_fig
         if timer is not None:
             rec["roofline"] = timer.roofline()
             kern = timer.summary()
@@ -360,42 +474,24 @@ def main():
             rec["kernels"] = kern
             covered = sum(d["ms_per_step"] for d in kern)
             rec["kernels_coverage"] = {"bracketed_ms_per_step": round(covered, 3), "frac_of_step": round(covered / ms, 3),
-                                       "note": "sum of bracketed launch durations / clean ms_per_step; the rest is torch glue "
-                                               "(loss, casts, fills) and launch gaps"}
+                                       "note": "sum of the raw HIP-event brackets (one per C-ABI launch, the timed step's own launch "
+                                               "sequence issued by the host; every bracket includes its event pair, ~"
+                                               f"{timer.overhead_s * 1e6:.1f} us, so the sum exceeds the replayed step) / ms_per_step"}
             if rec["roofline"]:
                 rec["roofline"]["launches"] = round(rec["roofline"]["launches"] / rsteps, 2)
                 attach_pmc_traffic(rec["roofline"], args.mixer)
+    job.close()
 
-    # other mixers of the same model, a few steps each (single GPU only: SURVEY 8d asks for the HEAD-default MHPermutMix
-    # and the DWT configuration next to the FFT headline)
-    variants = args.variants
-    if variants is None:
-        variants = "permut,dwt_embed" if (world == 1 and args.model == "spectre" and args.mixer == "fft" and not stand_in) else "none"
-    if variants != "none" and world == 1:
+    # single GPU, default workload: the other configurations SURVEY 8d asks for, each in the headline's launch mode
+    if rank == 0 and world == 1 and not stand_in and args.model == "spectre" and launch == "graph":
+        from spectre_vit import hip_ops
         del job
         torch.cuda.empty_cache()
-        out = {}
-        for mx in [v for v in variants.split(",") if v]:
-            vjob = Job(args, mx, dev, rank)
-            vsteps = max(5, min(args.steps, 20))
-            vel, vloss = timed_region(vjob, sync, vsteps, min(args.warmup, 5))
-            out[mx] = dict(value=round(args.batch * vsteps / vel, 1), unit="images/sec", ms_per_step=round(vel / vsteps * 1e3, 3),
-                           steps=vsteps, final_loss=round(float(vloss.item()), 4))
-            del vjob
-            torch.cuda.empty_cache()
-        rec["variants"] = out
-    if rank == 0 and world == 1 and not stand_in and args.model == "spectre" and not args.eager:
-        # single GPU: the product path for a launch-bound step is the captured graph; the eager figures stay in the line
-        gr = graph_replay(args, args.mixer, dev, args.steps, args.warmup)
-        rec["eager"] = {"value": rec["value"], "ms_per_step": rec["ms_per_step"], "final_loss": rec["final_loss"]}
-        rec["value"], rec["ms_per_step"], rec["final_loss"] = gr["images_per_sec"], gr["graph_ms_per_step"], gr["final_loss"]
-        rec["config"]["launch"] = "one HIP graph per step (spectre_vit.graph.GraphedTrainStep); eager figures under \"eager\""
-        rec["graph"] = gr
+        vsteps, vwarm = max(5, min(args.steps, 20)), min(args.warmup, 5)
         # Exact dead-row elimination, stated with its counterpart: SpectreViT reads only the CLS row of the stack's output (reference
         # spectre.py:198) and the last layer's feed-forward half works row by row, so by default it runs at the CLS rows only -- same
         # logits, loss and gradients (tests/test_gpu_bench_shapes.py checks both forms against the oracle).  The same graph-replayed
         # step with every row computed, as the reference does, is measured beside it.
-        from spectre_vit import hip_ops
         rec["config"]["last_layer_feed_forward"] = ("CLS rows only -- exact dead-row elimination: the model reads only the CLS row of the stack's output (reference spectre.py:198), so "
                                                   "the last layer's row-wise half (and its mixer's row 0) is computed for that row alone; logits, loss and EVERY parameter "
                                                   "gradient are those of the every-row computation (tests/test_gpu_bench_shapes.py runs both forms against the oracle); "
@@ -404,22 +500,26 @@ def main():
         if hip_ops.LAST_LAYER_CLS_ONLY and not args.no_every_row:
             hip_ops.LAST_LAYER_CLS_ONLY = False
             try:
-                full = graph_replay(args, args.mixer, dev, max(5, min(args.steps, 20)), min(args.warmup, 5))
+                rec["every_row_of_last_layer"] = side_leg(args, args.mixer, dev, sync, "graph", vsteps, vwarm)
             finally:
                 hip_ops.LAST_LAYER_CLS_ONLY = True
-            rec["every_row_of_last_layer"] = {"value": full["images_per_sec"], "unit": "images/sec", "ms_per_step": full["graph_ms_per_step"],
-                                              "final_loss": full["final_loss"]}
-        if "kernels_coverage" in rec:
-            rec["kernels_coverage"]["frac_of_step"] = round(rec["kernels_coverage"]["bracketed_ms_per_step"] / rec["ms_per_step"], 3)
-            rec["kernels_coverage"]["note"] = ("sum of bracketed launch durations (eager roofline pass; it brackets the layer weight "
-                                               "gradients one by one -- the timed step computes them in one batched launch, "
-                                               "~0.1 ms less) / graph-replayed ms_per_step; the rest is torch glue (loss, casts, "
-                                               "fills) and launch gaps")
+        variants = args.variants
+        if variants is None:
+            variants = "permut,dwt_embed" if args.mixer == "fft" else "none"
+        if variants != "none":
+            rec["variants"] = {mx: side_leg(args, mx, dev, sync, "graph", vsteps, vwarm) for mx in variants.split(",") if mx}
+        if not args.no_dp_sequence:
+            # what ONE rank of the N-GPU job executes, measured on this GPU: two graphs around the (one-rank) collective call
+            fc = one_rank_group(dev)
+            rec["dp_sequence"] = side_leg(args, args.mixer, dev, sync, "dp_graph", vsteps, vwarm, force_collective=fc)
+            rec["dp_sequence"]["collective"] = "torch.distributed all_reduce in a one-rank RCCL group" if fc else "skipped (no process group)"
+        if not args.no_script_leg:
+            rec["as_script"] = script_leg(args, args.mixer, dev, vsteps, vwarm)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.mixer, args.batch, args.cpu_steps)
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -44,6 +44,9 @@ enum {
     SPV_PATH_GATHER_LDS = 7,     /* LDS-staged MHPermutMix gather */
     SPV_PATH_GEMM_TN_WIDE = 9,   /* gemm_tn_wide_kernel (256 x 128 tile; M % 256 == 0, N % 128 == 0) */
     SPV_PATH_GEMM_TN_DMA = 8,    /* gemm_tn_dma_kernel (LDS-DMA ring; M, N % 128 == 0, K % 64 == 0) */
+    SPV_PATH_GEMM_TN_BATCH = 10, /* gemm_tn_batch_kernel: up to eight weight gradients in one launch (spv_gemm_tn_batch) */
+    SPV_PATH_GEMM_STRIP_POOL = 11, /* gemm_nt_strip_kernel<*, 2 / 3>: data gradient + pooled-broadcast term (spv_gemm_nt_pool_bwd) */
+    SPV_PATH_PERMUT_ROW0 = 12,   /* spv_permut_row0_fwd / _bwd: MHPermutMix at token row 0 (the CLS-only last layer) */
     SPV_PATH_COUNT = 16
 };
 long long spv_path_count(int which);
@@ -133,6 +136,10 @@ typedef struct spv_tn_problem {
 } spv_tn_problem;
 int spv_gemm_tn_batch(const spv_tn_problem* probs, int nprob, int K, int splits, void* workspace, const spv_fold_job* folds, int nfolds,
                       void* stream);
+/* The same call as two: part = 1 launches the batched GEMM only, part = 2 the split-K reduce + folds only (same arguments both
+ * times).  For a measuring caller that brackets each launch with its own pair of HIP events (bench.py's roofline pass). */
+int spv_gemm_tn_batch_part(const spv_tn_problem* probs, int nprob, int K, int splits, void* workspace, const spv_fold_job* folds,
+                           int nfolds, int part, void* stream);
 
 /* ---- SpectreLinear tail: out = dropout(GELU_erf(LayerNorm(h)) + adaptive_avg_pool(x)) ---------
  * spectre_vit/models/spectre/layers.py:85-101 (LN eps 1e-5, nn.GELU exact, AdaptiveAvgPool1d over the

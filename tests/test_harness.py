@@ -268,3 +268,217 @@ def test_graphed_train_step_matches_eager_steps():
     ls = [step3().item() for _ in range(4)]
     step3.close()
     assert len(set(ls)) == 4, ls
+
+
+def _small_graph_parts(dropout=0.0, layers=2, batch=64):
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    from spectre_vit.optim import FusedAdamW
+    cfg = dict(img_size=32, patch_size=4, in_channels=3, num_classes=100, embed_dim=512, num_encoders=layers, num_heads=16,
+               hidden_dim=768, activation="gelu")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(batch, 3, 32, 32, generator=g).to(dev)
+    labels = torch.randint(0, 100, (batch,), generator=g).to(dev)
+    torch.manual_seed(11)
+    m = SpectreViT(**cfg, dropout=dropout, mixer="fft").to(dev).train()
+    opt = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01, capturable=True, static_grads=True)
+    return m, opt, img, labels
+
+
+@pytest.mark.gpu
+def test_capture_refuses_gradients_that_moved():
+    """The fault of round 2 (a replayed graph / the optimizer's device pointer table holding addresses of gradients that
+    zero_grad(set_to_none=True) frees each step) must be a RuntimeError at capture time: FusedAdamW.step() inside a capture with a
+    gradient that is not where its table says raises instead of uploading a table mid-capture (optim.py, _table)."""
+    from spectre_vit.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    ps = [torch.randn(300, device=dev, requires_grad=True), torch.randn(7, 5, device=dev, requires_grad=True)]
+    opt = FusedAdamW(ps, lr=1e-3, capturable=True)
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    opt.step()
+    opt.step()   # same addresses twice: the table is settled
+    keep = [p.grad for p in ps]
+    opt.zero_grad(set_to_none=True)
+    for p in ps:
+        p.grad = torch.randn_like(p)   # fresh tensors while the old ones are still alive: new addresses
+    assert all(p.grad.data_ptr() != k.data_ptr() for p, k in zip(ps, keep))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="moved while a HIP graph is being captured"):
+        with torch.cuda.graph(graph):
+            opt.step()
+    torch.cuda.synchronize()
+    opt.step()   # outside a capture the table is simply rebuilt
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_static_grads_notices_a_swapped_gradient():
+    """static_grads=True skips the state walk once the table is settled, but compares every gradient address every step: a caller who
+    swaps a .grad gets the update of THAT tensor (round 2 re-verified the pointers only every 64th step: 63 silent writes through
+    stale pointers)."""
+    from spectre_vit.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    a = [torch.randn(1000, device=dev, requires_grad=True), torch.randn(33, device=dev, requires_grad=True)]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    oa = FusedAdamW(a, lr=1e-2, static_grads=True)
+    ob = torch.optim.AdamW(b, lr=1e-2)
+    fixed = [torch.randn_like(t) for t in a]
+    for step in range(6):
+        if step < 4:   # fixed addresses: after two look-ups the fast path serves the step
+            for t, g in zip(a, fixed):
+                g.normal_()
+                t.grad = g
+        else:          # the caller swaps in fresh tensors
+            for t in a:
+                t.grad = torch.randn_like(t)
+        for t, u in zip(a, b):
+            u.grad = t.grad.clone()
+        oa.step()
+        ob.step()
+        if step == 3:
+            assert oa._tables[0]["static"]
+        for x, y in zip(a, b):
+            assert torch.allclose(x, y, rtol=2e-6, atol=2e-7), (step, (x - y).abs().max().item())
+
+
+@pytest.mark.gpu
+def test_fused_adamw_load_state_dict_after_stepping():
+    """In-place resume / rollback: load_state_dict() on an optimizer that has already stepped must continue from the LOADED moments and
+    step count (the cached device table pointed at the orphaned old moment tensors and kept its own count)."""
+    from spectre_vit.optim import FusedAdamW
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    for capturable in (False, True):
+        a = [torch.randn(513, device=dev, requires_grad=True)]
+        b = [a[0].detach().clone().requires_grad_(True)]
+        oa, ob = FusedAdamW(a, lr=1e-2, capturable=capturable), torch.optim.AdamW(b, lr=1e-2)
+        grads = [torch.randn(513, device=dev) for _ in range(6)]
+        snap = None
+        for i, g in enumerate(grads):
+            a[0].grad, b[0].grad = g.clone(), g.clone()
+            oa.step(); ob.step()
+            if i == 1:
+                snap = (a[0].detach().clone(), oa.state_dict(), b[0].detach().clone(), ob.state_dict())
+                import copy
+                snap = copy.deepcopy(snap)
+        # roll both back to the state after step 2 and replay steps 3..4
+        with torch.no_grad():
+            a[0].copy_(snap[0]); b[0].copy_(snap[2])
+        oa.load_state_dict(snap[1]); ob.load_state_dict(snap[3])
+        for g in grads[2:4]:
+            a[0].grad, b[0].grad = g.clone(), g.clone()
+            oa.step(); ob.step()
+        assert float(oa.state_dict()["state"][0]["step"]) == 4.0
+        # (lr 1e-2: an update computed from the orphaned moments or the old step count is off by ~1e-2; device-side powf in the
+        # capturable bias correction accounts for the last-bit slack)
+        assert torch.allclose(a[0], b[0], rtol=2e-6, atol=2e-6), (capturable, (a[0] - b[0]).abs().max().item())
+
+
+@pytest.mark.gpu
+def test_eval_after_graph_replays_sees_the_new_weights():
+    """replays update the weights through raw pointers (no version bump, no optimizer hook), so the inference-time cache of
+    bf16 weight copies must be invalidated by the step itself: eval logits after replays == the logits of a freshly built model."""
+    from spectre_vit.graph import GraphedTrainStep
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    m, opt, img, labels = _small_graph_parts()
+    for grp in opt.param_groups:
+        grp["lr"] = 5e-2   # large steps: stale shadows would be obvious
+    step = GraphedTrainStep(m, opt, torch.nn.CrossEntropyLoss(), img, labels, warmup=1)
+
+    def ev(model):
+        model.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            out = model(img).float()
+        model.train()
+        return out
+
+    before = ev(m)
+    for _ in range(3):
+        step()
+    after = ev(m)
+    step.close()
+    fresh = SpectreViT(img_size=32, patch_size=4, in_channels=3, num_classes=100, embed_dim=512, num_encoders=2, num_heads=16,
+                       hidden_dim=768, activation="gelu", dropout=0.0, mixer="fft").to(img.device)
+    fresh.load_state_dict(m.state_dict())
+    assert torch.equal(after, ev(fresh))
+    assert (after - before).abs().max().item() > 0.05
+
+
+@pytest.mark.gpu
+def test_one_live_graphed_step_owns_the_seed_word():
+    """the dropout seed word is one device symbol.  A second live step is refused; rebinding `step = GraphedTrainStep(...)`
+    after close() works, and the OLD object's __del__ running later must not clear the new object's word (every replay would draw the
+    same masks)."""
+    import gc
+    from spectre_vit.graph import GraphedTrainStep
+    m, opt, img, labels = _small_graph_parts(dropout=0.3)
+    for grp in opt.param_groups:
+        grp["lr"] = 0.0
+        grp["weight_decay"] = 0.0
+    crit = torch.nn.CrossEntropyLoss()
+    old = GraphedTrainStep(m, opt, crit, img, labels, warmup=1)
+    with pytest.raises(RuntimeError, match="already live"):
+        GraphedTrainStep(m, opt, crit, img, labels, warmup=1)
+    old()
+    old.close()
+    new = GraphedTrainStep(m, opt, crit, img, labels, warmup=1)
+    del old            # the closed object's destructor runs now -- after `new` registered its own word
+    gc.collect()
+    ls = [new().item() for _ in range(4)]
+    new.close()
+    assert len(set(ls)) == 4, ls   # frozen weights, same batch: the losses differ only through fresh masks
+    with pytest.raises(RuntimeError, match="closed"):
+        new()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_graph", [False, True])
+def test_side_stream_batch_with_a_fresh_allocator(in_graph):
+    """the batched weight gradients start on the side stream while the patch embedding's backward allocates on the
+    main stream; the fold partials the batch's reduce reads had no owner once the flush returned.  With every tensor of the side
+    launches kept until the join, the default path (sinks + batch + side stream) equals the one-by-one path (SPV_WGRAD_BATCH off) from a
+    freshly emptied allocator, eagerly and inside a capture."""
+    from spectre_vit import hip_ops
+    from spectre_vit.dp import GradReducer
+    from spectre_vit.graph import GraphedTrainStep
+    crit = torch.nn.CrossEntropyLoss()
+
+    def grads_of(hold):
+        m, opt, img, labels = _small_graph_parts(layers=3, batch=96)   # (same seed: identical weights and batch every time)
+        for grp in opt.param_groups:
+            grp["lr"] = 0.0
+            grp["weight_decay"] = 0.0
+        keep = hip_ops._WGRAD_HOLD
+        hip_ops._WGRAD_HOLD = hold
+        try:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            if in_graph:
+                step = GraphedTrainStep(m, opt, crit, img, labels, warmup=1)
+                step()
+                torch.cuda.synchronize()
+                out = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+                step.close()
+                return out
+            red = GradReducer(m, always=True)
+            red.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = crit(m(img), labels)
+            loss.backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        finally:
+            hip_ops._WGRAD_HOLD = keep
+
+    before = hip_ops.PATH_COUNTS["wgrad_side_start"]
+    batched = grads_of(True)
+    assert hip_ops.PATH_COUNTS["wgrad_side_start"] > before
+    single = grads_of(False)
+    for k in batched:
+        ref = single[k]
+        err = (batched[k] - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+        assert err <= 2e-5, (k, err)   # other K-slices: the same sums to fp32 re-association; a clobbered partial would be O(1)

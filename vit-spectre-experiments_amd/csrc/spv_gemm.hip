@@ -1417,7 +1417,7 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
             static const bool lda0 = getenv("SPV_STRIP_LDA0") != nullptr;
             if (lda0) lda = 0;
             if (accumulate && acc_mb >= 2 && acc_mb <= 4) mb = acc_mb;
-            SPV_COUNT_PATH(accumulate ? SPV_PATH_GEMM_STRIP_ACC : SPV_PATH_GEMM_STRIP);
+            SPV_COUNT_PATH(bc != nullptr ? SPV_PATH_GEMM_STRIP_POOL : accumulate ? SPV_PATH_GEMM_STRIP_ACC : SPV_PATH_GEMM_STRIP);
             if (bc != nullptr && bc_pw % 8 != 0) {   // two-window epilogue: its own instantiation (in the one-window kernel it cost 6 %)
                 if (mb == 4) SPV_STRIP(4, 3);
                 else if (mb == 3) SPV_STRIP(3, 3);
@@ -1693,8 +1693,8 @@ extern "C" int spv_fold_multi(const spv_fold_job* folds, int nfolds, void* strea
     return 0;
 }
 
-extern "C" int spv_gemm_tn_batch(const spv_tn_problem* probs, int nprob, int K, int splits, void* workspace, const spv_fold_job* folds,
-                                 int nfolds, void* stream) {
+static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int splits, void* workspace, const spv_fold_job* folds,
+                              int nfolds, void* stream, int parts) {
     SPV_CHECK(probs != nullptr && nprob >= 1 && nprob <= TNB_MAX, "spv_gemm_tn_batch: 1..%d problems", TNB_MAX);
     SPV_CHECK(K > 0 && splits >= 1 && workspace != nullptr, "spv_gemm_tn_batch: K=%d splits=%d need a workspace", K, splits);
     SPV_CHECK(nfolds >= 0 && nfolds <= FJ_MAX && (nfolds == 0 || folds != nullptr), "spv_gemm_tn_batch: 0..%d fold jobs", FJ_MAX);
@@ -1722,14 +1722,30 @@ extern "C" int spv_gemm_tn_batch(const spv_tn_problem* probs, int nprob, int K, 
     }
     tb.first_tile[nprob] = tiles;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    SPV_COUNT_PATH(SPV_PATH_GEMM_TN);
-    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
-    SPV_LAUNCH_CHECK("spv_gemm_tn_batch");
-    FoldJobs fj{};
-    int fold_blocks = 0;
-    SPV_CHECK(fill_fold_jobs(folds, nfolds, fj, fold_blocks) == 0, "spv_gemm_tn_batch: bad fold job");
-    hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(fold_blocks + nprob * reduce_blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, tb,
-                       static_cast<const float*>(workspace), splits, reduce_blocks, fj);
-    SPV_LAUNCH_CHECK("spv_gemm_tn_batch(split-k reduce + fold)");
+    if (parts & 1) {
+        SPV_COUNT_PATH(SPV_PATH_GEMM_TN);
+        SPV_COUNT_PATH(SPV_PATH_GEMM_TN_BATCH);
+        hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+        SPV_LAUNCH_CHECK("spv_gemm_tn_batch");
+    }
+    if (parts & 2) {
+        FoldJobs fj{};
+        int fold_blocks = 0;
+        SPV_CHECK(fill_fold_jobs(folds, nfolds, fj, fold_blocks) == 0, "spv_gemm_tn_batch: bad fold job");
+        hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(fold_blocks + nprob * reduce_blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, tb,
+                           static_cast<const float*>(workspace), splits, reduce_blocks, fj);
+        SPV_LAUNCH_CHECK("spv_gemm_tn_batch(split-k reduce + fold)");
+    }
     return 0;
+}
+
+extern "C" int spv_gemm_tn_batch(const spv_tn_problem* probs, int nprob, int K, int splits, void* workspace, const spv_fold_job* folds,
+                                 int nfolds, void* stream) {
+    return gemm_tn_batch_impl(probs, nprob, K, splits, workspace, folds, nfolds, stream, 3);
+}
+
+extern "C" int spv_gemm_tn_batch_part(const spv_tn_problem* probs, int nprob, int K, int splits, void* workspace, const spv_fold_job* folds,
+                                      int nfolds, int part, void* stream) {
+    SPV_CHECK(part == 1 || part == 2, "spv_gemm_tn_batch_part: part must be 1 (the GEMM launch) or 2 (the reduce + fold launch), got %d", part);
+    return gemm_tn_batch_impl(probs, nprob, K, splits, workspace, folds, nfolds, stream, part);
 }

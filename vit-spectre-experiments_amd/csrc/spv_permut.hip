@@ -601,6 +601,7 @@ extern "C" int spv_permut_row0_fwd(const void* x, const uint32_t* idx, void* g0,
         hipLaunchKernelGGL(permut_row0_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, idx, (bf16_t*)g0, (bf16_t*)x0, d, n, embed);
     else
         hipLaunchKernelGGL(permut_row0_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)x, idx, (float*)g0, (float*)x0, d, n, embed);
+    SPV_COUNT_PATH(SPV_PATH_PERMUT_ROW0);
     SPV_LAUNCH_CHECK("spv_permut_row0_fwd");
     return 0;
 }
@@ -618,6 +619,7 @@ extern "C" int spv_permut_row0_bwd(const void* dg0, const void* dx0, const uint3
         hipLaunchKernelGGL(permut_row0_init_kernel<float>, dim3(cdiv(d / 8, 256), batch), dim3(256), 0, st, (const float*)dx0, (float*)dx, d, embed);
         hipLaunchKernelGGL(permut_row0_scatter_kernel<float>, dim3(cdiv(n, 256), batch), dim3(256), 0, st, (const float*)dg0, idx, (float*)dx, d, n);
     }
+    SPV_COUNT_PATH(SPV_PATH_PERMUT_ROW0);
     SPV_LAUNCH_CHECK("spv_permut_row0_bwd");
     return 0;
 }

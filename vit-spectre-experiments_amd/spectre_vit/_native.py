@@ -19,7 +19,8 @@ LIB_PATH = os.environ.get("SPV_LIB_PATH") or os.path.join(os.path.dirname(_HERE)
 c_vp, c_i, c_i64, c_u64, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
 # indices of include/spv.h's SPV_PATH_* enum (dispatch census, test aid)
-PATH = dict(gemm_strip=0, gemm_strip_acc=1, gemm_tn=2, tail_lc=3, tail_up=4, tail_ln=5, fnet_mfma=6, gather_lds=7, gemm_tn_dma=8, gemm_tn_wide=9)
+PATH = dict(gemm_strip=0, gemm_strip_acc=1, gemm_tn=2, tail_lc=3, tail_up=4, tail_ln=5, fnet_mfma=6, gather_lds=7, gemm_tn_dma=8, gemm_tn_wide=9,
+            gemm_tn_batch=10, gemm_strip_pool=11, permut_row0=12)
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/spv.h one to one
 SIGNATURES = {
@@ -60,6 +61,7 @@ SIGNATURES = {
     "spv_fold_multi": [c_vp, c_i, c_vp],
     "spv_gemm_tn_fold": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_vp, c_i, c_vp],
     "spv_gemm_tn_batch": [c_vp, c_i, c_i, c_i, c_vp, c_vp, c_i, c_vp],
+    "spv_gemm_tn_batch_part": [c_vp, c_i, c_i, c_i, c_vp, c_vp, c_i, c_i, c_vp],
     "spv_small_sl_supported": [c_i, c_i, c_i],
     "spv_small_sl_partial_floats": [c_i, c_i],
     "spv_small_sl_fwd": [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_vp],
@@ -120,6 +122,7 @@ _lib = None
 # live kernel timing (bench.py's roofline pass): when set, every entry point that launches on a stream is bracketed with HIP
 # events by ``timer.bracket(name, ints, launch)``; ints = the integer arguments (shapes, dtype codes, flags) in header order
 timer = None
+hint = 0   # set by a caller right before a bracketed call whose algorithmic work is not a function of its integer arguments
 _LAUNCHERS = {}
 
 
@@ -137,7 +140,8 @@ def load():
             fn.argtypes = argtypes
             fn.restype = _RESTYPES.get(name, c_i)
             if argtypes and argtypes[-1] is c_vp and name not in _NO_STATUS and name != "spv_fnet_make_twiddle":
-                _LAUNCHERS[name] = [i for i, t in enumerate(argtypes) if t in (c_i, c_i64)]
+                _LAUNCHERS[name] = ([i for i, t in enumerate(argtypes) if t in (c_i, c_i64)],
+                                    [i for i, t in enumerate(argtypes[:-1]) if t is c_vp])
         if lib.spv_version() != 1:
             raise RuntimeError(f"libspv_hip.so ABI version {lib.spv_version()} != 1")
         _lib = lib
@@ -148,7 +152,12 @@ def call(name, *args):
     """Invoke a status-returning entry point; raise RuntimeError(spv_last_error()) on failure."""
     lib = load()
     if timer is not None and name in _LAUNCHERS:
-        ints = tuple(int(args[i]) for i in _LAUNCHERS[name])
+        global hint
+        ii, pi = _LAUNCHERS[name]
+        # key of a bracket: the integer arguments in header order, then a bit mask of the pointer arguments that are NULL (optional
+        # outputs change a kernel's traffic), then the caller's work hint (algorithmic flops / bytes the integers do not determine)
+        ints = tuple(int(args[i]) for i in ii) + (sum(1 << b for b, i in enumerate(pi) if not args[i]), hint)
+        hint = 0
         box = []
         timer.bracket(name, ints, lambda: box.append(getattr(lib, name)(*args)))
         rc = box[0]

@@ -25,10 +25,15 @@ RESERVED_CUS = 16  # CUs left to RCCL while gradients are exchanged during the b
 
 class GradReducer:
     def __init__(self, module: torch.nn.Module, bucket_mb: float = 8.0, process_group=None, reduce_dtype=None,
-                 tail_mb: float = 2.0, always: bool = False):
+                 tail_mb: float = 2.0, always: bool = False, overlap: bool = True):
         """always=True: lay the buckets out even in a single process (no exchange then): every gradient gets a FIXED address, which
-        a captured HIP graph and the one-launch optimizer's pointer table need (spectre_vit/graph.py, spectre_vit/optim.py)."""
+        a captured HIP graph and the one-launch optimizer's pointer table need (spectre_vit/graph.py, spectre_vit/optim.py).
+        overlap=False: the hooks launch nothing; ``finish()`` exchanges ALL buckets with one all-reduce over the flat buffer they are
+        views of (spectre_vit.graph.GraphedDPStep: the backward pass is a replayed HIP graph, there is no host in it to launch a
+        collective from, and a 13 MB exchange is one call).  No CUs are set aside for RCCL then: nothing runs beside it."""
         self.group = process_group
+        self.overlap = bool(overlap)
+        self.flat = None
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.reduce_dtype = reduce_dtype
@@ -41,7 +46,7 @@ class GradReducer:
         self._bucket_of = {}
         if not self.params or (self.world == 1 and not always):
             return  # single process: no exchange, gradients stay ordinary per-parameter tensors
-        if self.params[0].is_cuda and self.world > 1:
+        if self.params[0].is_cuda and self.world > 1 and self.overlap:
             # the layer GEMMs run one workgroup per CU and cannot share a CU with a resident RCCL channel: leave 16 CUs to the
             # collectives that overlap the backward (free at the layer shapes, see spv.h: spv_set_reserved_cus)
             try:
@@ -74,9 +79,16 @@ class GradReducer:
         if cur:
             groups.append(cur)
         groups.append(list(reversed(tail)))
+        # ONE allocation behind all buckets (each bucket a 256-byte-aligned slice of it): the non-overlapped exchange is a single
+        # all-reduce over it; the overlapped one still goes bucket by bucket
+        starts, total = [], 0
+        for ps in groups:
+            starts.append(total)
+            total += (sum(p.numel() for p in ps) + 63) // 64 * 64
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
         for bi, ps in enumerate(groups):
             n = sum(p.numel() for p in ps)
-            flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+            flat = self.flat[starts[bi]:starts[bi] + n]
             off = 0
             views = []
             for p in ps:
@@ -124,7 +136,7 @@ class GradReducer:
             self.adopted_numel += p.numel()
         p.grad = v
         b["pending"] -= 1
-        if b["pending"] == 0 and self.world > 1:
+        if b["pending"] == 0 and self.world > 1 and self.overlap:
             self._launch(b)
 
     def finish(self):
@@ -132,6 +144,9 @@ class GradReducer:
         if self.world == 1:
             return
         inv = 1.0 / self.world
+        if not self.overlap:
+            self.allreduce_flat()
+            return
         for b in self.buckets:
             if b["handle"] is None:  # a parameter of this bucket received no gradient this step: its slot is stale -> zero
                 for q, v in zip(b["params"], b["views"]):
@@ -144,6 +159,25 @@ class GradReducer:
                 b["stage"] = None
             if not self._avg:
                 b["flat"].mul_(inv)
+
+    def allreduce_flat(self, force: bool = False):
+        """the non-overlapped exchange: every bucket in ONE all-reduce (mean over ranks) on the caller's stream order.  The caller
+        guarantees that every slot holds this step's gradient (a replayed graph writes all of them; eager callers with parameters that
+        may receive no gradient use the overlapped mode, whose finish() zeroes stale slots).  force=True issues the collective in a
+        one-rank process group too (bench.py --dp-sequence: the launch sequence of a rank, measured on one GPU)."""
+        if self.flat is None or (self.world == 1 and not (force and dist.is_available() and dist.is_initialized())):
+            return
+        buf = self.flat
+        if self.reduce_dtype is not None and self.reduce_dtype != torch.float32:
+            stage = buf.to(self.reduce_dtype)
+            dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.group)
+            buf.copy_(stage)
+            if self.world > 1:
+                buf.mul_(1.0 / self.world)
+            return
+        dist.all_reduce(buf, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group)
+        if not self._avg and self.world > 1:
+            buf.mul_(1.0 / self.world)
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0, process_group=None):

@@ -18,9 +18,10 @@ _CHUNK = 2048
 
 class FusedAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, capturable=False, static_grads=False):
-        """static_grads=True: the caller promises fixed gradient addresses (spectre_vit.dp.GradReducer(model, always=True), or a
-        captured graph): after two identical look-ups the per-step pointer check is skipped (re-verified every 64th step) -- the
-        63-parameter walk is 0.3 ms of host time per step otherwise."""
+        """static_grads=True: the caller expects fixed gradient addresses (spectre_vit.dp.GradReducer(model, always=True), or a
+        captured graph): after two identical look-ups a step only COMPARES the gradient addresses with the table's (one tuple of
+        ``p.grad.data_ptr()`` per group, every step: a caller that swapped a ``.grad`` gets a rebuilt table, never a write through a
+        stale pointer) and skips the state walk and the table build -- 0.3 ms of host time per step otherwise."""
         if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
             raise ValueError(f"FusedAdamW: invalid hyper-parameters lr={lr} betas={betas} eps={eps} weight_decay={weight_decay}")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=capturable))
@@ -30,7 +31,9 @@ class FusedAdamW(torch.optim.Optimizer):
     def _table(self, gi, ps):
         """device-side pointer / chunk tables of one parameter group; rebuilt only when a pointer moved (in the steady state the
         caching allocator hands the same gradient blocks back every step; with GradReducer the gradients live in fixed buckets)"""
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        # (the moment tensors are part of the key: load_state_dict() on an optimizer that has already stepped replaces them)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
+                    for p in ps)
         t = self._tables.get(gi)
         if t is not None and t["key"] == key:
             return t
@@ -62,6 +65,15 @@ class FusedAdamW(torch.optim.Optimizer):
         self._tables[gi] = t
         return t
 
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces the per-parameter state (moments, step count): drop the device tables so that the next step() reads
+        the loaded step count and points at the loaded moment tensors (in-place resume / rollback of an optimizer that has stepped)."""
+        super().load_state_dict(state_dict)
+        self._tables = {}
+        for st in self.state.values():
+            if isinstance(st.get("step"), torch.Tensor):
+                st["step"] = st["step"].float()
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -71,9 +83,9 @@ class FusedAdamW(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             t = self._tables.get(gi)
             b1, b2 = group["betas"]
-            if t is not None and t.get("static") and t["calls"] % 64:
-                # fixed gradient addresses (GradReducer(always=True) / a captured graph): nothing to look up; the pointers are
-                # re-verified every 64th step
+            if (t is not None and t.get("static")
+                    and t["grad_ptrs"] == tuple(0 if p.grad is None else p.grad.data_ptr() for p in group["params"])):
+                # fixed gradient addresses (GradReducer(always=True) / a captured graph), verified: nothing to look up
                 t["calls"] += 1
             else:
                 ps = [p for p in group["params"] if p.grad is not None]
@@ -91,7 +103,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 old_key = t["key"] if had else None
                 t = self._table(gi, ps)
                 if "step" not in t:  # ONE step counter per group, shared by its parameters' state entries
-                    prev = next((self.state[p]["step"] for p in ps if self.state[p]["step"] is not None), None)
+                    prev = next((self.state[p]["step"] for p in ps if self.state[p].get("step") is not None), None)
                     dev = ps[0].device if group["capturable"] else "cpu"
                     t["step"] = prev.to(dev).clone() if prev is not None else torch.zeros((), dtype=torch.float32, device=dev)
                     t["host_step"] = int(float(t["step"]))
@@ -99,6 +111,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     self.state[p]["step"] = t["step"]
                 # static once the same table has served two consecutive look-ups
                 t["static"] = self.static_grads and had and old_key == t["key"]
+                # what the fast path compares every step: the gradient address of EVERY parameter of the group (0 = no gradient)
+                t["grad_ptrs"] = tuple(0 if p.grad is None else p.grad.data_ptr() for p in group["params"])
                 t["calls"] = 1
             if group["capturable"]:
                 t["step"] += 1.0
