@@ -282,8 +282,10 @@ int spv_rfft_real(const void* x, void* y, int rows, int dim, int transpose, int 
 
 /* ---- Haar DWT mixers ('dwt_embed' along dim, 'dwt_token' along tokens) ---------------------------
  * named in spectre_vit/models/spectre/spectre.py:33-34; only call site repl/dwt_experiments.py:56.
- * Orthonormal pairs a=(x0+x1)/sqrt2, d=(x0-x1)/sqrt2, output [a_J | d_J | ... | d_1]; an odd trailing
- * element passes through.  inverse=1 applies the adjoint (= inverse = the backward). */
+ * Pairs a=(x0+x1)/sqrt2, d=(x0-x1)/sqrt2 (PyWavelets' 'haar'), output [a_J | d_J | ... | d_1] (pywt.wavedec's order).  `inverse`
+ * bit 0: apply the adjoint (the backward; = the inverse when the map is orthonormal).  bit 1 selects what happens to the unpaired
+ * last element of an odd length: 0 = it passes through into the approximation band (orthonormal), 1 = pywt's mode="zero" of the
+ * reference's call (dwt_experiments.py:56): paired with a zero, a_last = x_last / sqrt2, the duplicate d_last is not stored. */
 int spv_haar_dwt(const void* x, void* y, int batch, int tokens, int dim, int axis, int levels, int inverse,
                  int dtype, void* scratch, void* stream);
 

@@ -194,11 +194,20 @@ def fnet_mix_bwd(dy):
     return fnet_mix_fwd(dy)
 
 
-def haar_level_fwd(x, axis):
-    """One orthonormal Haar level along `axis`: pairs (x0,x1)->((x0+x1)/sqrt2, (x0-x1)/sqrt2);
-    an odd trailing element is passed through into the approximation band (keeps the map
-    orthonormal and shape preserving; PARITY UNPINNED -- no model code in the reference, only
-    dwt_experiments.py:56; pywt 'haar'/'zero' agrees on every full pair)."""
+def haar_level_fwd(x, axis, mode="passthrough"):
+    """One Haar level along `axis`: pairs (x0,x1)->((x0+x1)/sqrt2, (x0-x1)/sqrt2) -- the pair convention PyWavelets documents for
+    'haar' = 'db1' (``pywt.dwt([1,2,3,4],'db1')`` -> cA [2.1213, 4.9497], cD [-0.7071, -0.7071]; tests/test_oracle_golden.py holds the
+    documented vectors).  PARITY UNPINNED against the reference: it has no DWT model code, only dwt_experiments.py:56.
+
+    An odd trailing element x_L has no partner.  mode="passthrough" (the default): it is copied into the approximation band, which
+    keeps the map orthonormal and shape preserving.  mode="zero": the convention of the reference's only call
+    (``DWTForward(J=3, wave="haar", mode="zero")``, dwt_experiments.py:56 -- pywt's 'zero' signal extension): the signal is extended
+    by a zero, so the last pair is (x_L, 0) and gives cA_last = cD_last = x_L / sqrt2; pywt returns both (ceil(L/2) + ceil(L/2) =
+    L + 1 coefficients).  A shape-preserving mixer has L slots: the band tensor keeps every cA and drops that LAST detail coefficient,
+    which is a copy of the last approximation coefficient (no information is lost; the map is no longer orthonormal: x_L is scaled
+    by 1/sqrt2).  haar_level_pywt_zero returns pywt's full (cA, cD) pair for the comparison."""
+    if mode not in ("passthrough", "zero"):
+        raise ValueError(mode)
     x = np.moveaxis(x, axis, -1)
     L = x.shape[-1]
     h = L // 2
@@ -206,11 +215,22 @@ def haar_level_fwd(x, axis):
     a = (e + o) / SQRT2
     d = (e - o) / SQRT2
     if L % 2:
-        a = np.concatenate([a, x[..., -1:]], axis=-1)
+        last = x[..., -1:] if mode == "passthrough" else x[..., -1:] / SQRT2
+        a = np.concatenate([a, last], axis=-1)
     return np.moveaxis(a, -1, axis), np.moveaxis(d, -1, axis)
 
 
-def haar_level_bwd(da, dd, axis):
+def haar_level_pywt_zero(x):
+    """(cA, cD) of one level along the last axis as ``pywt.dwt(x, 'haar', mode='zero')`` returns them: ceil(L/2) coefficients each, an
+    odd signal extended by one zero."""
+    x = np.asarray(x)
+    if x.shape[-1] % 2:
+        x = np.concatenate([x, np.zeros(x.shape[:-1] + (1,), x.dtype)], axis=-1)
+    return (x[..., 0::2] + x[..., 1::2]) / SQRT2, (x[..., 0::2] - x[..., 1::2]) / SQRT2
+
+
+def haar_level_bwd(da, dd, axis, mode="passthrough"):
+    """adjoint of haar_level_fwd"""
     da = np.moveaxis(da, axis, -1)
     dd = np.moveaxis(dd, axis, -1)
     h = dd.shape[-1]
@@ -219,23 +239,23 @@ def haar_level_bwd(da, dd, axis):
     dx[..., 0:2 * h:2] = (da[..., :h] + dd) / SQRT2
     dx[..., 1:2 * h:2] = (da[..., :h] - dd) / SQRT2
     if L % 2:
-        dx[..., -1] = da[..., -1]
+        dx[..., -1] = da[..., -1] if mode == "passthrough" else da[..., -1] / SQRT2
     return np.moveaxis(dx, -1, axis)
 
 
-def haar_dwt_fwd(x, axis=-1, levels=1):
-    """J-level Haar DWT mixer, output = concat[a_J, d_J, ..., d_1] along `axis` (same length).
-    axis=-1: 'dwt_embed', axis=-2: 'dwt_token' (spectre.py:33-34)."""
+def haar_dwt_fwd(x, axis=-1, levels=1, mode="passthrough"):
+    """J-level Haar DWT mixer, output = concat[a_J, d_J, ..., d_1] along `axis` (same length) -- the coefficient order of
+    ``pywt.wavedec`` ([cA_J, cD_J, ..., cD_1]).  axis=-1: 'dwt_embed', axis=-2: 'dwt_token' (spectre.py:33-34)."""
     bands = []
     a = x
     for _ in range(levels):
-        a, d = haar_level_fwd(a, axis)
+        a, d = haar_level_fwd(a, axis, mode)
         bands.append(d)
     return np.concatenate([a] + bands[::-1], axis=axis)
 
 
-def haar_dwt_bwd(dy, axis=-1, levels=1):
-    """Adjoint (== inverse, the transform is orthonormal)."""
+def haar_dwt_bwd(dy, axis=-1, levels=1, mode="passthrough"):
+    """Adjoint (== inverse for mode "passthrough": that transform is orthonormal)."""
     L = dy.shape[axis]
     lens = []
     cur = L
@@ -248,7 +268,7 @@ def haar_dwt_bwd(dy, axis=-1, levels=1):
     for h in lens[::-1]:
         dd = dy[..., off:off + h]
         off += h
-        da = haar_level_bwd(da, dd, -1)
+        da = haar_level_bwd(da, dd, -1, mode)
     return np.moveaxis(da, -1, axis)
 
 
@@ -507,7 +527,7 @@ def mixer_fwd(x, lp, mixer):
     if mixer == "dwt_embed":
         return haar_dwt_fwd(x, -1, lp.get("dwt_levels", 1)), None
     if mixer == "dwt_token":
-        return haar_dwt_fwd(x, -2, lp.get("dwt_levels", 1)), None
+        return haar_dwt_fwd(x, -2, lp.get("dwt_levels", 1), lp.get("dwt_mode", "passthrough")), None
     raise ValueError(mixer)
 
 
@@ -519,7 +539,7 @@ def mixer_bwd(dy, lp, mixer, cache):
     if mixer == "dwt_embed":
         return haar_dwt_bwd(dy, -1, lp.get("dwt_levels", 1)), {}
     if mixer == "dwt_token":
-        return haar_dwt_bwd(dy, -2, lp.get("dwt_levels", 1)), {}
+        return haar_dwt_bwd(dy, -2, lp.get("dwt_levels", 1), lp.get("dwt_mode", "passthrough")), {}
     raise ValueError(mixer)
 
 

@@ -507,3 +507,35 @@ def test_held_weight_gradients_run_as_one_batch():
     for k in single:
         err = (single[k] - batched[k]).norm().item() / max(single[k].norm().item(), 1e-30)
         assert err < 2e-6, (k, err)
+
+
+def test_forward_hooks_on_the_stack_fire_and_see_reference_tensors():
+    """SpectreViT's fast paths step around ``encoder_blocks.__call__`` / the last layer's ``__call__`` / ``mlp_head.__call__``
+    (CLS-row-only forms).  With a forward hook on any of them the model runs the reference's call sequence instead: the hook fires and
+    sees the reference-shaped tensors; logits and gradients are those of the fast path."""
+    import numpy as np
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    cfg = dict(img_size=16, patch_size=4, in_channels=3, num_classes=100, embed_dim=64, num_encoders=2, num_heads=4, hidden_dim=96,
+               dropout=0.0, activation="gelu")
+    for mixer in ("fft", "permut"):
+        torch.manual_seed(3)
+        m = SpectreViT(**cfg, mixer=mixer).to("cuda").train()
+        x = torch.randn(4, 3, 16, 16, device="cuda")
+        y = torch.randint(0, 100, (4,), device="cuda")
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        fast = (m(x).detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+        m.zero_grad(set_to_none=True)
+        seen = {}
+        hooks = [m.encoder_blocks.register_forward_hook(lambda mod, a, out: seen.__setitem__("stack", tuple(out.shape))),
+                 m.encoder_blocks.layers[-1].register_forward_hook(lambda mod, a, out: seen.__setitem__("last", tuple(out.shape))),
+                 m.mlp_head.register_forward_hook(lambda mod, a, out: seen.__setitem__("head", tuple(out.shape)))]
+        out = m(x)
+        torch.nn.functional.cross_entropy(out, y).backward()
+        assert seen == {"stack": (4, 17, 64), "last": (4, 17, 64), "head": (4, 100)}, seen
+        assert torch.allclose(out, fast[0], rtol=1e-5, atol=1e-6)
+        for k, p in m.named_parameters():
+            err = (p.grad - fast[1][k]).abs().max().item() / (fast[1][k].abs().max().item() + 1e-30)
+            assert err < 1e-4, (mixer, k, err)
+        for h in hooks:
+            h.remove()
+        assert not m._observed()

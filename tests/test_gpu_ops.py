@@ -429,6 +429,43 @@ def test_haar_dwt(ops, dtype, shape, axis, levels):
     check(X.grad, O.haar_dwt_bwd(dy, axis - 3, levels), tol, "dx")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,axis,levels", [((2, 65, 32), 1, 1), ((2, 65, 32), 1, 3), ((3, 5, 33), 2, 2), ((2, 65, 512), 1, 2)])
+def test_haar_dwt_zero_mode(ops, dtype, shape, axis, levels):
+    """mode="zero" (pywt's extension of odd lengths, the reference's dwt_experiments.py:56): forward and adjoint vs the oracle"""
+    rng = np.random.default_rng(levels + axis)
+    x, dy = q(rng.standard_normal(shape), dtype), q(rng.standard_normal(shape), dtype)
+    X = t(x, dtype).requires_grad_(True)
+    Y = ops.HaarDWTFn.apply(X, axis, levels, True)
+    Y.backward(t(dy, dtype))
+    tol = 1e-6 if dtype == torch.float32 else 1.5e-2
+    check(Y, O.haar_dwt_fwd(x, axis - 3, levels, "zero"), tol, "y")
+    check(X.grad, O.haar_dwt_bwd(dy, axis - 3, levels, "zero"), tol, "dx")
+
+
+def test_haar_kernel_matches_pywavelets_documented_vectors(ops):
+    """the HIP kernel on the vectors PyWavelets' documentation prints for 'db1' (tests/test_oracle_golden.py cites them): pair
+    convention, sign of the detail band, wavedec's coefficient order"""
+    from test_oracle_golden import PYWT_DWT_DB1, PYWT_WAVEDEC_DB1_L2
+    x, cA, cD = PYWT_DWT_DB1
+    for axis, shape in ((2, (1, 1, 4)), (1, (1, 4, 1))):
+        y = ops.HaarDWTFn.apply(torch.tensor(x, dtype=torch.float32, device=dev()).reshape(shape), axis, 1)
+        assert np.abs(y.cpu().numpy().reshape(-1) - np.concatenate([cA, cD])).max() < 1e-6
+    x, cA2, cD2, cD1 = PYWT_WAVEDEC_DB1_L2
+    for zero in (False, True):
+        for axis, shape in ((2, (1, 1, 8)), (1, (1, 8, 1))):
+            y = ops.HaarDWTFn.apply(torch.tensor(x, dtype=torch.float32, device=dev()).reshape(shape), axis, 2, zero)
+            assert np.abs(y.cpu().numpy().reshape(-1) - np.concatenate([cA2, cD2, cD1])).max() < 1e-6
+    # the mixer module itself, token axis, 65 tokens, mode "zero": 33 approximation + 32 detail coefficients of pywt's 33 + 33
+    from spectre_vit.modules.mixers import HaarDWTMixer
+    rng = np.random.default_rng(0)
+    xs = rng.standard_normal((2, 65, 16))
+    y = HaarDWTMixer("token", 1, "zero")(torch.tensor(xs, dtype=torch.float32, device=dev())).cpu().numpy()
+    cA, cD = O.haar_level_pywt_zero(np.moveaxis(xs, 1, -1))
+    ref = np.moveaxis(np.concatenate([cA, cD[..., :-1]], axis=-1), -1, 1)
+    assert np.abs(y - ref).max() < 1e-6
+
+
 @pytest.mark.parametrize("B,N", [(3, 65), (2, 17), (5, 64), (2, 2)])
 def test_fnet_layernorm_residual_fused(ops, B, N):
     """x1 = LayerNorm1(Re(fft2(x))) + x as one kernel each way (bf16, D = 512): forward, dx, dgamma, dbeta against the oracle
@@ -769,7 +806,7 @@ def test_fold_rides_in_the_split_k_reduce(ops, monkeypatch, rows, n, k):
 
     assert ops._fold_rides(bf, rows, n, k)
     rode = run()
-    monkeypatch.setenv("SPV_NO_FOLD_RIDE", "1")
+    monkeypatch.setattr(ops, "FOLD_RIDE", False)
     assert not ops._fold_rides(bf, rows, n, k)
     plain = run()
     for a, c, name in zip(rode, plain, ("dx", "dW", "dbias", "dgamma", "dbeta")):

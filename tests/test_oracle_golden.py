@@ -223,6 +223,58 @@ def test_haar_dwt_orthonormal_roundtrip():
     close(O.haar_dwt_fwd(x, -1, 1), np.array([[4.0, 8.0, -2.0, -4.0]]) / np.sqrt(2))
 
 
+# Known-answer vectors of the Haar DWT as PRINTED in PyWavelets' documentation (the library behind pytorch_wavelets' DWTForward, the
+# reference's only DWT call: repl/dwt_experiments.py:56; `pywavelets>=1.9.0` in its pyproject.toml:28; not installed here):
+#   "Discrete Wavelet Transform (DWT)", pywt.dwt:      >>> (cA, cD) = pywt.dwt([1, 2, 3, 4, 5, 6], 'db1')  is the 6-sample form of
+#                                                       >>> cA, cD = pywt.dwt([1, 2, 3, 4], 'db1')
+#                                                       cA = [2.12132034 4.94974747]   cD = [-0.70710678 -0.70710678]
+#   pywt.wavedec:                                      >>> coeffs = pywt.wavedec([1, 2, 3, 4, 5, 6, 7, 8], 'db1', level=2)
+#                                                       cA2 = [ 5. 13.]   cD2 = [-2. -2.]   cD1 = [-0.70710678 x 4]
+# ('db1' is the Haar wavelet.)  They pin the pair convention (a = (x0 + x1)/sqrt2, d = (x0 - x1)/sqrt2: the SIGN of the detail band)
+# and the band order of a multi-level transform ([cA_J, cD_J, ..., cD_1]) -- the two choices a from-scratch Haar can get wrong.
+PYWT_DWT_DB1 = (np.array([1.0, 2.0, 3.0, 4.0]), np.array([2.12132034, 4.94974747]), np.array([-0.70710678, -0.70710678]))
+PYWT_WAVEDEC_DB1_L2 = (np.arange(1.0, 9.0), np.array([5.0, 13.0]), np.array([-2.0, -2.0]), np.full(4, -0.70710678))
+
+
+def test_haar_matches_pywavelets_documented_vectors():
+    x, cA, cD = PYWT_DWT_DB1
+    a, d = O.haar_level_fwd(x[None], -1)
+    close(a[0], cA, rtol=0, atol=5e-9)
+    close(d[0], cD, rtol=0, atol=5e-9)
+    close(O.haar_dwt_fwd(x[None], -1, 1)[0], np.concatenate([cA, cD]), rtol=0, atol=5e-9)   # the mixer's band layout: [cA | cD]
+    x, cA2, cD2, cD1 = PYWT_WAVEDEC_DB1_L2
+    close(O.haar_dwt_fwd(x[None], -1, 2)[0], np.concatenate([cA2, cD2, cD1]), rtol=0, atol=5e-9)   # wavedec's coefficient order
+    for mode in ("passthrough", "zero"):   # even lengths: the two conventions for an unpaired element never apply
+        close(O.haar_dwt_fwd(x[None], -1, 2, mode)[0], np.concatenate([cA2, cD2, cD1]), rtol=0, atol=5e-9)
+
+
+def test_haar_zero_mode_odd_length():
+    """mode="zero" (the reference's DWTForward(..., mode="zero"), dwt_experiments.py:56): an odd signal is extended by one zero, so
+    pywt returns ceil(L/2) + ceil(L/2) coefficients with cA_last = cD_last = x_last / sqrt2 (by the pair convention above on the pair
+    (x_last, 0): derived, not a printed vector).  The shape-preserving mixer keeps every cA and all but that duplicate last cD."""
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((3, 65))
+    cA, cD = O.haar_level_pywt_zero(x)
+    assert cA.shape == cD.shape == (3, 33)
+    close(cA[:, -1], x[:, -1] / np.sqrt(2), rtol=1e-15)
+    close(cD[:, -1], cA[:, -1], rtol=1e-15)   # the coefficient the mixer drops is a copy of one it keeps
+    y = O.haar_dwt_fwd(x, -1, 1, "zero")
+    assert y.shape == x.shape
+    close(y, np.concatenate([cA, cD[:, :-1]], axis=-1), rtol=1e-15)
+    close(O.haar_level_pywt_zero(np.array([1.0, 2.0, 3.0]))[0], np.array([3.0, 3.0]) / np.sqrt(2), rtol=1e-15)
+    close(O.haar_level_pywt_zero(np.array([1.0, 2.0, 3.0]))[1], np.array([-1.0, 3.0]) / np.sqrt(2), rtol=1e-15)
+    # pass-through differs from it in exactly one slot (x_last vs x_last / sqrt2) ...
+    yp = O.haar_dwt_fwd(x, -1, 1, "passthrough")
+    diff = np.abs(yp - y)
+    assert (diff[:, :32] == 0).all() and (diff[:, 33:] == 0).all()
+    close(yp[:, 32], x[:, -1], rtol=1e-15)
+    # ... and the backward is the exact adjoint in both modes, over several levels and along the token axis too
+    for mode in ("passthrough", "zero"):
+        for shape, axis, J in [((2, 65, 8), -2, 1), ((2, 65, 8), -2, 3), ((2, 7, 33), -1, 2)]:
+            u, v = rng.standard_normal(shape), rng.standard_normal(shape)
+            close((O.haar_dwt_fwd(u, axis, J, mode) * v).sum(), (u * O.haar_dwt_bwd(v, axis, J, mode)).sum(), rtol=1e-12)
+
+
 def test_distill_loss_gradient_numeric():
     rng = np.random.default_rng(2)
     s, t = rng.standard_normal((3, 7)), rng.standard_normal((3, 7))

@@ -1,4 +1,5 @@
 cd /tmp; export TMPDIR=/tmp
+# (lab switches: needs `make -C vit-spectre-experiments_amd/csrc lab`, SPV_LAB=1 and SPV_LIB_PATH=.../lib/libspv_hip_lab.so in the environment)
 R=$GRAFT_REPO_ROOT
 for S in 1 0; do
   rm -rf /tmp/prof_s$S

@@ -27,6 +27,17 @@ int spv_set_error(const char* fmt, ...);
 extern long long g_spv_path_counts[SPV_PATH_COUNT];
 #define SPV_COUNT_PATH(which) (++g_spv_path_counts[which])
 
+// Development switches.  The product library reads NO environment variable: every A/B, tuning and diagnosis switch below exists only
+// in the lab build (`make lab` -> lib/libspv_hip_lab.so, compiled with -DSPV_LAB and selected by tools/ through SPV_LIB_PATH).
+#ifdef SPV_LAB
+#include <cstdlib>
+#define SPV_LAB_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define SPV_LAB_SET(name) (getenv(name) != nullptr)
+#else
+#define SPV_LAB_INT(name, dflt) (dflt)
+#define SPV_LAB_SET(name) false
+#endif
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------- bf16 <-> f32 (device)

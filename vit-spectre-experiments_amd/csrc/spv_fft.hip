@@ -822,8 +822,9 @@ __global__ __launch_bounds__(256) void rfft_real_kernel(const void* __restrict__
 
 // one Haar level over the leading `len` positions of the chosen axis; positions >= len are copied
 __global__ __launch_bounds__(256) void haar_level_kernel(const void* __restrict__ src, void* __restrict__ dst, int64_t total, int N,
-                                                         int D, int axis_tokens, int len, int inverse, int bf) {
+                                                         int D, int axis_tokens, int len, int inverse, int bf, int zero_mode) {
     const float r = 0.70710678118654752440f;
+    const float odd_scale = zero_mode ? r : 1.0f;
     const int lh = len >> 1, la = len - lh;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int d = (int)(e % D);
@@ -837,10 +838,10 @@ __global__ __launch_bounds__(256) void haar_level_kernel(const void* __restrict_
         if (p >= len) v = at(p);
         else if (!inverse) {
             if (p < lh) v = (at(2 * p) + at(2 * p + 1)) * r;
-            else if (p < la) v = at(len - 1);
+            else if (p < la) v = at(len - 1) * odd_scale;   // the unpaired last element: copied (pass-through) or paired with a zero
             else { const int q = p - la; v = (at(2 * q) - at(2 * q + 1)) * r; }
         } else {
-            if ((len & 1) && p == len - 1) v = at(la - 1);
+            if ((len & 1) && p == len - 1) v = at(la - 1) * odd_scale;
             else {
                 const int q = p >> 1;
                 const float a = at(q), dd = at(la + q);
@@ -941,10 +942,10 @@ extern "C" int spv_fnet_mix(const void* x, void* y, const void* add_in, const fl
     SPV_CHECK(dtype == SPV_F32 || dtype == SPV_BF16, "spv_fnet_mix: bad dtype %d", dtype);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int bf = dtype == SPV_BF16;
-    static const bool no_v2 = getenv("SPV_FNET_NO_V2") != nullptr;  // tuning / A-B aid
+    static const bool no_v2 = SPV_LAB_SET("SPV_FNET_NO_V2");  // tuning / A-B aid
     if (bf && dim == V2D && tokens >= 2 && tokens <= 65 && !no_v2) {
         SPV_CHECK(twiddle != nullptr, "spv_fnet_mix: twiddle table required");
-        static const int stagger_env = getenv("SPV_FNET_STAGGER") ? atoi(getenv("SPV_FNET_STAGGER")) : -1;
+        static const int stagger_env = SPV_LAB_INT("SPV_FNET_STAGGER", -1);
         const int v2_stagger = stagger_env >= 0 ? stagger_env : (batch >= 512 ? 1 : 0);  // x 8128 cycles (~3.5 us)
         const int rows = std::max(2 * ((tokens + 1) / 2), 2 * (tokens / 2 + 1));
         const size_t lds = (size_t)rows * V2RS;
@@ -1006,6 +1007,9 @@ extern "C" int spv_haar_dwt(const void* x, void* y, int batch, int tokens, int d
     SPV_CHECK(levels >= 1 && levels <= 16, "spv_haar_dwt: levels=%d", levels);
     SPV_CHECK(dtype == SPV_F32 || dtype == SPV_BF16, "spv_haar_dwt: bad dtype %d", dtype);
     SPV_CHECK(levels == 1 || scratch != nullptr, "spv_haar_dwt: scratch needed for levels > 1");
+    SPV_CHECK(inverse >= 0 && inverse <= 3, "spv_haar_dwt: inverse=%d (bit 0: adjoint, bit 1: 'zero' extension of odd lengths)", inverse);
+    const int zero_mode = (inverse >> 1) & 1;
+    inverse &= 1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int lens[16];
     int cur = axis == 1 ? tokens : dim;
@@ -1016,7 +1020,7 @@ extern "C" int spv_haar_dwt(const void* x, void* y, int batch, int tokens, int d
     for (int i = 0; i < levels; ++i) {
         const int l = inverse ? levels - 1 - i : i;
         void* dst = ((levels - 1 - i) % 2 == 0) ? y : scratch;
-        static const bool generic = getenv("SPV_HAAR_GENERIC") != nullptr;   // A/B switch
+        static const bool generic = SPV_LAB_SET("SPV_HAAR_GENERIC");   // A/B switch
         if (!generic && axis == 2 && dtype == SPV_BF16 && dim % 8 == 0 && lens[l] % 16 == 0 &&
             (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
             const int64_t rows = (int64_t)batch * tokens;
@@ -1028,7 +1032,7 @@ extern "C" int spv_haar_dwt(const void* x, void* y, int batch, int tokens, int d
             continue;
         }
         hipLaunchKernelGGL(haar_level_kernel, dim3(grid), dim3(256), 0, st, src, dst, total, tokens, dim, axis == 1, lens[l], inverse,
-                           dtype == SPV_BF16);
+                           dtype == SPV_BF16, zero_mode);
         SPV_LAUNCH_CHECK("spv_haar_dwt");
         src = dst;
     }
@@ -1038,12 +1042,12 @@ extern "C" int spv_haar_dwt(const void* x, void* y, int batch, int tokens, int d
 
 // ---- mixer + LayerNorm-1 + residual as one kernel each way (bf16, dim 512, tokens <= 65: the shapes of fnet_mfma_kernel)
 extern "C" int spv_fnet_ln_supported(int tokens, int dim, int dtype) {
-    static const bool off = getenv("SPV_FNET_NO_V2") != nullptr || getenv("SPV_FNET_NO_FUSE") != nullptr;
+    static const bool off = SPV_LAB_SET("SPV_FNET_NO_V2") || SPV_LAB_SET("SPV_FNET_NO_FUSE");
     return (!off && dtype == SPV_BF16 && dim == V2D && tokens >= 2 && tokens <= 65) ? 1 : 0;
 }
 
 static int fnet_ln_stagger(int batch) {
-    static const int env = getenv("SPV_FNET_LN_STAGGER") ? atoi(getenv("SPV_FNET_LN_STAGGER")) : 0;  // x 8128 cycles; tuning aid
+    static const int env = SPV_LAB_INT("SPV_FNET_LN_STAGGER", 0);  // x 8128 cycles; tuning aid
     return batch >= 512 ? env : 0;
 }
 static size_t fnet_v2_lds(int tokens) { return (size_t)std::max(2 * ((tokens + 1) / 2), 2 * (tokens / 2 + 1)) * V2RS; }
@@ -1248,7 +1252,7 @@ __global__ __launch_bounds__(D / 2) void fnet_cls_bwd_kernel(const T* __restrict
 }  // namespace
 
 extern "C" int spv_fnet_cls_supported(int tokens, int dim, int dtype) {
-    static const bool off = getenv("SPV_FNET_NO_CLS") != nullptr;
+    static const bool off = SPV_LAB_SET("SPV_FNET_NO_CLS");
     return (!off && (dtype == SPV_BF16 || dtype == SPV_F32) && (dim == 256 || dim == 512 || dim == 1024) && tokens >= 1) ? 1 : 0;
 }
 

@@ -807,7 +807,7 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
 static int g_reserved_cus = 0;
 
 inline bool strip_plan(int M, int N, int K, int& MB, int& nstrips, int& groups, int& base, int& rem) {
-    static const int enabled = getenv("SPV_GEMM_STRIP") ? atoi(getenv("SPV_GEMM_STRIP")) : 1;
+    static const int enabled = SPV_LAB_INT("SPV_GEMM_STRIP", 1);
     if (!enabled || N % 256 != 0 || N > 16384 || K % 128 != 0 || K < 128 || M < 8192) return false;   // (Base width: the MHPermutMix data gradient has N = 9216)
     nstrips = N / 256;
     const int nblk = cdiv(M, 32);
@@ -1092,6 +1092,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
     store_acc_tile<TO>(acc, tw_smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr, nullptr, 0, 0, wm * 64, wn * 64);
 }
 
+#ifdef SPV_LAB   // measured slower inside the training step: kept for the lab build only
 // ---------------------------------------------------------------------------------------------------------
 // TN contraction, LDS-DMA variant: the weight gradients of the encoder layers, dW[768 x 512] = dh^T . x over 33 280 rows
 // (backward of layers.py:86).  Same output tile (128 x 128) as gemm_tn_kernel, but
@@ -1275,6 +1276,7 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(const bf16_t* __restri
         }
     }
 }
+#endif  // SPV_LAB
 
 template <typename TO>
 __device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ ws, const float* __restrict__ bias, TO* __restrict__ C, int M, int N,
@@ -1411,11 +1413,13 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
     hipLaunchKernelGGL((gemm_nt_strip_kernel<MBV, EPIV>), dim3(nwg), dim3(512), 0, st, static_cast<const bf16_t*>(A),       \
                        static_cast<const bf16_t*>(B), bias, static_cast<bf16_t*>(C), M, K, lda, ldb, ldc, nstrips, base, rem, nwg, \
                        static_cast<const bf16_t*>(bc), bc_pw, bc ? N / bc_pw : 0)
-            static const int acc_mb = getenv("SPV_STRIP_ACC_MB") ? atoi(getenv("SPV_STRIP_ACC_MB")) : 0;  // tuning aid
+            static const int acc_mb = SPV_LAB_INT("SPV_STRIP_ACC_MB", 0);  // tuning aid
             // diagnosis only (wrong results): every A row reads row 0, i.e. A always hits in L2 -- separates "HBM latency x one K-tile of
             // prefetch" from "L2 -> LDS rate" as the bound of the K loop
-            static const bool lda0 = getenv("SPV_STRIP_LDA0") != nullptr;
+#ifdef SPV_LAB
+            static const bool lda0 = SPV_LAB_SET("SPV_STRIP_LDA0");
             if (lda0) lda = 0;
+#endif
             if (accumulate && acc_mb >= 2 && acc_mb <= 4) mb = acc_mb;
             SPV_COUNT_PATH(bc != nullptr ? SPV_PATH_GEMM_STRIP_POOL : accumulate ? SPV_PATH_GEMM_STRIP_ACC : SPV_PATH_GEMM_STRIP);
             if (bc != nullptr && bc_pw % 8 != 0) {   // two-window epilogue: its own instantiation (in the one-window kernel it cost 6 %)
@@ -1444,16 +1448,19 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
         // direct-to-LDS double-buffered kernel for long reductions (measured: 896 vs 795 TFLOP/s at 4096^3, 755 vs 700 on
         // the 512 x 8192 x 33280 weight gradient); the skinny K <= 1024 layer GEMMs are faster on the register-staged
         // kernel (42 vs 50 us at 33280 x 768 x 512: three workgroups per CU instead of two)
-        static const int force_kb = getenv("SPV_GEMM_KB") ? atoi(getenv("SPV_GEMM_KB")) : 0;  // tuning aid: 64 / 128 / -1 (off)
+        static const int force_kb = SPV_LAB_INT("SPV_GEMM_KB", 0);  // tuning aid: 64 / 128 / -1 (off)
         // K <= 1024 (the layer GEMMs) stays on the register-staged kernel: the three-stage 64-byte-row ring measures the
         // same step time (2.978 vs 2.972 ms over three alternating runs) and 4 us more per isolated launch
         if (force_kb >= 0 && K % GBK == 0 && k_per_split % GBK == 0 && (force_kb || kend_len(K, k_per_split) > 1024)) {
             const int kb = force_kb ? force_kb : 128;
+            (void)kb;
+#ifdef SPV_LAB
             if (kb == 64)
                 hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 64, 3>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                    static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
                                    accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf, t_drop_p, t_drop_seed);
             else
+#endif
                 hipLaunchKernelGGL((gemm_nt_glds_kernel<TO, 128, 2>), grid, dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                    static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), ws, M, N, K, lda, ldb, ldc, k_per_split,
                                    accumulate, tiles_n, tiles_m * tiles_n, splits, rg, gs, roff, bias2d, bc, bc_pw, bc_bf, t_drop_p, t_drop_seed);
@@ -1590,9 +1597,11 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
     float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
     // opt-in (SPV_TN_DMA=1): isolated it is 3-6 % faster than the register-staged kernel (52.5 vs 54.5 us incl. the reduce), inside
     // the training step it measured SLOWER (68 vs 47 us per launch), so the register-staged kernel stays the default
-    static const int use_dma = getenv("SPV_TN_DMA") ? atoi(getenv("SPV_TN_DMA")) : 0;
-    static const int use_wide = getenv("SPV_TN_WIDE") ? atoi(getenv("SPV_TN_WIDE")) : 1;
-    static const int wide_min = getenv("SPV_TN_WIDE_MIN") ? atoi(getenv("SPV_TN_WIDE_MIN")) : 4;   // tuning aid
+    static const int use_dma = SPV_LAB_INT("SPV_TN_DMA", 0);
+    (void)use_dma;
+    static const int use_wide = SPV_LAB_INT("SPV_TN_WIDE", 1);
+    static const int wide_min = SPV_LAB_INT("SPV_TN_WIDE_MIN", 4);   // tuning aid
+#ifdef SPV_LAB
     if (use_dma && M % BM == 0 && N % BN == 0 && K % TDK == 0 && k_per_split % TDK == 0 && (ws != nullptr || ldc % 4 == 0)) {
         const int nwg = tiles_m * tiles_n * splits;
         if (out_dtype == SPV_BF16) {
@@ -1606,7 +1615,9 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
         }
         SPV_LAUNCH_CHECK("spv_gemm_tn(dma)");
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN_DMA);
-    } else if (use_wide && splits >= wide_min && M % TWM == 0 && N % BN == 0 && (M / TWM) * tiles_n * splits >= 128) {
+    } else
+#endif
+    if (use_wide && splits >= wide_min && M % TWM == 0 && N % BN == 0 && (M / TWM) * tiles_n * splits >= 128) {
         // the 256 x 128 tile (8 waves, one workgroup per CU): the split-K layer weight gradients (SPV_TN_WIDE=0 for the 128 x 128
         // kernel).  Measured in graph mode, alternating: 2.372 vs 2.385 ms/step -- 1.6 us per launch; without split-K (the MHPermutMix
         // weight gradient, 512 x 8192 x 33 280) it is SLOWER (651 vs 510 us), hence splits >= 4
@@ -1625,7 +1636,7 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN_WIDE);
     } else {
     dim3 grid(tiles_m * tiles_n * splits);
-    static const int depth = getenv("SPV_TN_DEPTH") ? atoi(getenv("SPV_TN_DEPTH")) : 3;  // tuning aid: 1 = one K-tile in flight
+    static const int depth = SPV_LAB_INT("SPV_TN_DEPTH", 3);  // tuning aid: 1 = one K-tile in flight
 #define SPV_TN(TOV, DV)                                                                                                     \
     hipLaunchKernelGGL((gemm_tn_kernel<TOV, DV>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (TOV*)C, ws, M, N, K, \
                        lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n, splits)

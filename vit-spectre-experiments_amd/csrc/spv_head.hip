@@ -395,7 +395,7 @@ __global__ __launch_bounds__(HT) void ce_bwd_kernel(const float* __restrict__ z,
 }  // namespace
 
 extern "C" int spv_small_sl_supported(int rows, int n, int k) {
-    static const bool off = getenv("SPV_NO_SMALL_HEAD") != nullptr;  // A/B switch: the generic SpectreLinear path
+    static const bool off = SPV_LAB_SET("SPV_NO_SMALL_HEAD");  // A/B switch: the generic SpectreLinear path
     return (!off && rows > 0 && rows <= 4096 && n > 0 && n <= MAXN && k > 0 && k <= MAXK && n <= k) ? 1 : 0;
 }
 extern "C" int64_t spv_small_sl_partial_floats(int rows, int n) { return (int64_t)cdiv(rows, HR) * 3 * n; }

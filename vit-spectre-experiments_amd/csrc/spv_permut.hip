@@ -481,7 +481,7 @@ extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g
                       (total / 4) % PT == 0,
                   "spv_permut_gather_fwd: unsupported pool window %d", pool_window);
     }
-    static const bool wide_only = getenv("SPV_PERMUT_WIDE") != nullptr;  // A/B switch: the round-1 kernels
+    static const bool wide_only = SPV_LAB_SET("SPV_PERMUT_WIDE");  // A/B switch: the round-1 kernels
     const int64_t total_e = (int64_t)heads * d;
     if (!wide_only && dtype == SPV_BF16 && compact_ok(d) && (size_t)d * 4 <= (size_t)LDS_LIMIT &&
         (pooled == nullptr || ((pool_window == 8 || pool_window == 16 || pool_window == 32) && (total_e / 8) % PT == 0))) {
@@ -519,8 +519,8 @@ extern "C" int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* 
     const uint32_t* inv = idx + (size_t)heads * d;
     const size_t es = dtype == SPV_BF16 ? 2 : 4;
     const bool aligned = ((size_t)d * es) % 16 == 0 && d % 4 == 0;
-    static const bool wide_only = getenv("SPV_PERMUT_WIDE") != nullptr;
-    static const bool no_dma = getenv("SPV_GATHER_NO_DMA") != nullptr;   // A/B switch
+    static const bool wide_only = SPV_LAB_SET("SPV_PERMUT_WIDE");
+    static const bool no_dma = SPV_LAB_SET("SPV_GATHER_NO_DMA");   // A/B switch
     if (!wide_only && !no_dma && dtype == SPV_BF16 && compact_ok(d) && ((size_t)d * 2) % 1024 == 0 && (size_t)d * 4 <= (size_t)LDS_LIMIT &&
         d <= 8 * PT * C_IT && (((uintptr_t)dg | (uintptr_t)dx) & 15) == 0) {
         const Compact c = compact_of(idx, (int64_t)heads * d);

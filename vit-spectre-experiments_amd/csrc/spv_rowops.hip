@@ -1421,7 +1421,7 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
         LC_FWD(12, 48) // 3072 -> 768: linear3 at the Base width (exact windows of 4)
 #undef LC_FWD
     }
-    static const bool no_wide = getenv("SPV_TAIL_NO_WIDE") != nullptr;   // A/B switch
+    static const bool no_wide = SPV_LAB_SET("SPV_TAIL_NO_WIDE");   // A/B switch
     if (!no_wide && n == RW * 64 * WCO && k_in * WR == n && (out_dtype == SPV_BF16) == (dtype == SPV_BF16) &&
         (((uintptr_t)h | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) {
         const dim3 wgrid(std::min(rows, 2048));
@@ -1474,7 +1474,7 @@ static int tail_bwd_impl(const void* dout, const void* h, const float* mean, con
         LC_BWD(12, 48)
 #undef LC_BWD
     }
-    static const bool no_wide = getenv("SPV_TAIL_NO_WIDE") != nullptr;   // A/B switch
+    static const bool no_wide = SPV_LAB_SET("SPV_TAIL_NO_WIDE");   // A/B switch
     if (!no_wide && up.src == nullptr && n == RW * 64 * WCO && k_in * WR == n && (dout_dtype == SPV_BF16) == (dtype == SPV_BF16) &&
         (((uintptr_t)h | (uintptr_t)dout | (uintptr_t)dh | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)partials) & 15) == 0) {
         // one workgroup per row at a time; the slab count is the same function of rows as everywhere (spv_tail_bwd_parts)
@@ -1509,7 +1509,7 @@ extern "C" int spv_spectre_tail_bwd(const void* dout, const void* h, const float
 }
 
 extern "C" int spv_tail_up_supported(int n, int k_in, int dtype) {
-    static const bool off = getenv("SPV_TAIL_NO_UP") != nullptr;
+    static const bool off = SPV_LAB_SET("SPV_TAIL_NO_UP");
     return (!off && n == 768 && k_in == 512 && check_dtype(dtype)) ? 1 : 0;
 }
 
@@ -1526,7 +1526,7 @@ extern "C" int spv_spectre_tail_bwd_up(const void* dout, const void* h, const fl
 
 // ---- linear3 tail + residual + LayerNorm-2 as one kernel each way (512 outputs from 768 inputs: the lane-contiguous <8, 12> kernels)
 extern "C" int spv_tail_ln_supported(int n, int k_in, int dtype) {
-    static const bool off = getenv("SPV_TAIL_NO_FUSE") != nullptr;
+    static const bool off = SPV_LAB_SET("SPV_TAIL_NO_FUSE");
     return (!off && n == 512 && k_in == 768 && check_dtype(dtype)) ? 1 : 0;
 }
 extern "C" int64_t spv_tail_ln_partial_floats(int n) { return (int64_t)BWD_MAX_WG * 5 * n; }
@@ -1573,7 +1573,7 @@ extern "C" int spv_spectre_tail_ln_bwd(const void* dout2, const void* f3, const 
 }
 
 extern "C" int spv_haar_ln_supported(int dim, int dtype) {
-    static const bool off = getenv("SPV_HAAR_NO_FUSE") != nullptr;   // A/B switch
+    static const bool off = SPV_LAB_SET("SPV_HAAR_NO_FUSE");   // A/B switch
     return (!off && dtype == SPV_BF16 && (dim == 512 || dim == 1024)) ? 1 : 0;
 }
 
@@ -1631,7 +1631,7 @@ extern "C" int spv_add_layernorm_bwd(const void* dout, const void* a, const void
     SPV_CHECK(pick_cfg(n, cfg), "spv_add_layernorm_bwd: unsupported row length %d", n);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int wgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
-    static const bool no_fast = getenv("SPV_ADDLN_GENERIC") != nullptr;   // A/B switch
+    static const bool no_fast = SPV_LAB_SET("SPV_ADDLN_GENERIC");   // A/B switch
     const bool aligned16 = (((uintptr_t)dout | (uintptr_t)a | (uintptr_t)(b ? b : a) | (uintptr_t)din | (uintptr_t)gamma) & 15) == 0;
     if (!no_fast && aligned16 && (n == 512 || n == 768 || n == 1024)) {
         const size_t lds = (size_t)2 * n * sizeof(float);

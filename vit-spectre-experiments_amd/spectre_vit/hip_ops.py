@@ -386,9 +386,19 @@ def _gemm_launch(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, 
                  _p(workspace), _stream())
 
 
-_SIDE_STREAM = os.environ.get("SPV_SIDE_STREAM", "1") != "0"
-_SIDE_MIN_FLOPS = float(os.environ.get("SPV_SIDE_MIN_FLOPS", "1e11"))  # weight gradients at least this big fork to the side stream
-_TN_DMA = os.environ.get("SPV_TN_DMA", "0") == "1"  # must match the library's own switch (spv_gemm.hip)
+# Development switches: read from the environment ONLY in lab mode (SPV_LAB=1, together with the lab build of the library:
+# `make -C csrc lab`, SPV_LIB_PATH=.../libspv_hip_lab.so).  In the product configuration every one of them is its default; tests
+# that exercise an alternative path set the module attribute.
+_LAB = os.environ.get("SPV_LAB") == "1"
+
+
+def _lab(name, default):
+    return os.environ.get(name, default) if _LAB else default
+
+
+_SIDE_STREAM = _lab("SPV_SIDE_STREAM", "1") != "0"
+_SIDE_MIN_FLOPS = float(_lab("SPV_SIDE_MIN_FLOPS", "1e11"))  # weight gradients at least this big fork to the side stream
+_TN_DMA = _lab("SPV_TN_DMA", "0") == "1"  # must match the lab library's own switch (spv_gemm.hip)
 _side_streams = {}
 _side_keep = []  # tensors a side-stream kernel still reads/writes: kept alive until the join
 
@@ -427,9 +437,11 @@ FOLD_RIDERS = 6    # fold jobs a layer's own reduce launch carries
 _held_wgrads = []  # (dh, x, dw address, rows, n, k, fold or None)
 WGRAD_BATCH = 8    # problems per launch (csrc/spv_gemm.hip TNB_MAX)
 BATCH_FOLDS = 16   # fold jobs the batch's reduce launch carries (FJ_MAX)
-_WGRAD_HOLD = os.environ.get("SPV_WGRAD_BATCH", "1") != "0"
-_WGRAD_SPLITS = int(os.environ.get("SPV_WGRAD_BATCH_SPLITS", "0"))   # tuning aid: 0 = chosen per batch
-_WGRAD_SIDE = os.environ.get("SPV_WGRAD_SIDE", "1") != "0"            # the batch starts on the side stream beside the embedding's backward
+_WGRAD_HOLD = _lab("SPV_WGRAD_BATCH", "1") != "0"
+_WGRAD_SPLITS = int(_lab("SPV_WGRAD_BATCH_SPLITS", "0"))   # tuning aid: 0 = chosen per batch
+_WGRAD_SIDE = _lab("SPV_WGRAD_SIDE", "1") != "0"            # the batch starts on the side stream beside the embedding's backward
+NO_HOLD = bool(_lab("SPV_NO_HOLD", ""))         # nothing is held back (the launch sequence of the overlapped data-parallel path)
+FOLD_RIDE = not _lab("SPV_NO_FOLD_RIDE", "")    # tail folds ride in their layer's weight-gradient reduce
 
 
 # Under data parallelism the overlapped (eager) exchange needs every gradient as soon as its node has run, so nothing is held.  A
@@ -440,7 +452,7 @@ TIME_HELD = False   # bench.py's roofline pass: bracket the launch sequence the 
 
 
 def _hold_ok():
-    if os.environ.get("SPV_NO_HOLD") or (_timing() and not TIME_HELD):
+    if NO_HOLD or (_timing() and not TIME_HELD):
         return False
     if HOLD_UNDER_DP:
         return True
@@ -584,7 +596,7 @@ def _hold_fold(partials, outs, sinks, parts, n):
 
 def _fold_rides(dtype, rows, n, k):
     """the tail backward's fold can ride in this weight gradient's split-K reduce (bf16 TN path on the main stream)"""
-    return (dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0 and not os.environ.get("SPV_NO_FOLD_RIDE")
+    return (dtype == torch.bfloat16 and n % 8 == 0 and k % 8 == 0 and FOLD_RIDE
             and not (_SIDE_STREAM and not _timing() and 2.0 * rows * n * k >= _SIDE_MIN_FLOPS))
 
 
@@ -918,26 +930,26 @@ class RfftRealFn(torch.autograd.Function):
         return dx.reshape(shape)
 
 
-def _haar_raw(x, axis, levels, inverse):
+def _haar_raw(x, axis, levels, inverse, zero_mode=False):
     B, N, D = x.shape
     xc = x.contiguous()
     y = torch.empty_like(xc)
     scratch = torch.empty_like(xc) if levels > 1 else None
-    _native.call("spv_haar_dwt", _p(xc), _p(y), B, N, D, axis, levels, inverse, _dt(xc), _p(scratch), _stream())
+    _native.call("spv_haar_dwt", _p(xc), _p(y), B, N, D, axis, levels, inverse | (2 if zero_mode else 0), _dt(xc), _p(scratch), _stream())
     return y
 
 
 class HaarDWTFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, axis, levels):
+    def forward(ctx, x, axis, levels, zero_mode=False):
         _require_gpu(x)
-        ctx.meta = (axis, levels)
-        return _haar_raw(x, axis, levels, 0)
+        ctx.meta = (axis, levels, bool(zero_mode))
+        return _haar_raw(x, axis, levels, 0, zero_mode)
 
     @staticmethod
     def backward(ctx, dy):
-        axis, levels = ctx.meta
-        return _haar_raw(dy, axis, levels, 1), None, None
+        axis, levels, zero_mode = ctx.meta
+        return _haar_raw(dy, axis, levels, 1, zero_mode), None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
