@@ -46,6 +46,7 @@ enum {
     SPV_PATH_GEMM_TN_DMA = 8,    /* gemm_tn_dma_kernel (LDS-DMA ring; M, N % 128 == 0, K % 64 == 0) */
     SPV_PATH_GEMM_TN_BATCH = 10, /* gemm_tn_batch_kernel: up to eight weight gradients in one launch (spv_gemm_tn_batch) */
     SPV_PATH_GEMM_STRIP_POOL = 11, /* gemm_nt_strip_kernel<*, 2 / 3>: data gradient + pooled-broadcast term (spv_gemm_nt_pool_bwd) */
+    SPV_PATH_GEMM_ROWS = 13,     /* gemm_nt_rows_kernel: few-rows NT GEMM, one 32 x 32 tile per workgroup, no split-K (the CLS-only last layer) */
     SPV_PATH_PERMUT_ROW0 = 12,   /* spv_permut_row0_fwd / _bwd: MHPermutMix at token row 0 (the CLS-only last layer) */
     SPV_PATH_COUNT = 16
 };

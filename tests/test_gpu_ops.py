@@ -68,6 +68,30 @@ def test_gemm_nt(ops, dtype, M, N, K, splits):
     check(C2, a @ b.T + c2, TOL[dtype], "gemm accumulate")
 
 
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 512), (512, 512, 768), (500, 776, 528), (2048, 264, 16), (33, 2048, 1040), (512, 512, 48)])
+def test_gemm_nt_rows_kernel(ops, M, N, K, out_dtype):
+    """The few-rows kernel (bf16 operands, M <= 2048, one 32 x 32 tile per workgroup, K dealt over four waves; the CLS-only last layer's
+    512-row GEMMs) against fp64: ragged M and N, a K that is not a multiple of the per-wave batch, bias, accumulate, both output types;
+    the census proves the path; nothing is written outside the output."""
+    from spectre_vit import _native
+    rng = np.random.default_rng(M + N + K)
+    a, b = q(rng.standard_normal((M, K)), torch.bfloat16), q(rng.standard_normal((N, K)) * 0.1, torch.bfloat16)
+    bias = rng.standard_normal(N)
+    A, B, bi = t(a, torch.bfloat16), t(b, torch.bfloat16), t(bias)
+    C = torch.full((M + 1, N), 7.0, dtype=out_dtype, device=dev())
+    before = _native.call("spv_path_count", _native.PATH["gemm_rows"])
+    ops._gemm(A, B, bi, C, M, N, K, K, K, N)
+    assert _native.call("spv_path_count", _native.PATH["gemm_rows"]) == before + 1
+    tol = 1e-4 if out_dtype == torch.float32 else TOL[torch.bfloat16]
+    check(C[:M], a @ b.T + bias, tol, "rows gemm")
+    assert bool((C[M] == 7.0).all()), "wrote past the last row"
+    C0 = t(rng.standard_normal((M, N)), out_dtype)
+    c0 = n64(C0)
+    ops._gemm(A, B, None, C0, M, N, K, K, K, N, 1)
+    check(C0, a @ b.T + c0, tol, "rows gemm accumulate")
+
+
 @pytest.mark.parametrize("M,N,K", [(33280, 768, 512), (33280, 512, 768), (33270, 256, 128), (20000, 512, 384), (33280, 1024, 256),
                                    (94203, 512, 128), (33280, 1536, 512), (16640, 2048, 128)])
 def test_gemm_nt_strip_kernel(ops, M, N, K):

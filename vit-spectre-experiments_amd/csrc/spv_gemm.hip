@@ -81,6 +81,9 @@ __device__ __forceinline__ void store_acc_tile(f32x16 (*acc)[2], unsigned char* 
     constexpr int SLD = 68;
     const bool vec_c = ((size_t)ldc * sizeof(TO)) % 16 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
     const bool vec_ws = (N & 3) == 0;
+    // the replay-time seed word is ONE global load per tile, issued here (inside the chunk loop it was a dependent L2 round trip in
+    // front of every chunk's hash: 7.5 of the embedding GEMM's 25 us)
+    const uint64_t seed_live = drop_p > 0.0f ? live_seed(drop_seed) : 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         __syncthreads();
@@ -148,14 +151,19 @@ __device__ __forceinline__ void store_acc_tile(f32x16 (*acc)[2], unsigned char* 
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                 }
                 if (b2 != nullptr) {
+                    if (vec_ws && (reinterpret_cast<uintptr_t>(bias2d) & 15) == 0) {   // two 16-byte loads (eight 4-byte ones: 34 -> us of the embedding GEMM)
+                        const float4 p0 = *reinterpret_cast<const float4*>(b2), p1 = *reinterpret_cast<const float4*>(b2 + 4);
+                        v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+                    } else {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] += b2[u];
+                        for (int u = 0; u < 8; ++u) v[u] += b2[u];
+                    }
                 }
                 if (drop_p > 0.0f) {
                     // the nn.Dropout that follows the projection (spectre.py:156), on the flat index of the contiguous output: the
                     // mask spv_dropout / spv_embed_bwd derive from the same seed
                     const size_t fi = (size_t)orow * ldc + col0;
-                    const unsigned key = dropout_row_key(live_seed(drop_seed), (uint64_t)fi >> 12);
+                    const unsigned key = dropout_row_key(seed_live, (uint64_t)fi >> 12);
                     const unsigned c0 = (unsigned)(fi & 4095);
                     const float inv_keep = 1.0f / (1.0f - drop_p);
 #pragma unroll
@@ -191,7 +199,7 @@ __device__ __forceinline__ void store_acc_tile(f32x16 (*acc)[2], unsigned char* 
                     if (b2 != nullptr) x += b2[u];
                     if (drop_p > 0.0f) {
                         const size_t fi = (size_t)orow * ldc + col0 + u;
-                        x *= dropout_scale(dropout_row_key(live_seed(drop_seed), (uint64_t)fi >> 12), (unsigned)(fi & 4095), drop_p, 1.0f / (1.0f - drop_p));
+                        x *= dropout_scale(dropout_row_key(seed_live, (uint64_t)fi >> 12), (unsigned)(fi & 4095), drop_p, 1.0f / (1.0f - drop_p));
                     }
                     if (accumulate) x += load_out<TO>(cp + u);
                     store_out<TO>(cp + u, x);
@@ -837,6 +845,78 @@ inline bool strip_plan(int M, int N, int K, int& MB, int& nstrips, int& groups, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Few-rows NT GEMM (M <= 2048: the CLS-only last layer's feed-forward half, 512 rows): C[M,N] (+)= A[M,K] . B[N,K]^T (+ bias).
+// Such a problem is 24 tiles of 128 x 128: the tile kernel needs split-K to reach more than 24 CUs, i.e. a slab workspace and a
+// reduce launch -- 9.5 + 5.5 us for 0.4 GFLOP, both at the launch floor.  Here ONE 32 x 32 output tile per 4-wave workgroup (384
+// workgroups at 512 x 768), the K range dealt over the four waves and joined in LDS, and no operand staging at all: both operands
+// are K-contiguous, so the 16 bytes a lane feeds one v_mfma_f32_32x32x16_bf16 with are 16 contiguous bytes of one row -- a plain
+// global_load_dwordx4 from the L2-resident operands, every load of a wave's K share in flight before its first MFMA.
+template <typename TO>
+__global__ __launch_bounds__(256) void gemm_nt_rows_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, const float* __restrict__ bias,
+                                                           TO* __restrict__ C, int M, int N, int K, int lda, int ldb, int ldc, int accumulate,
+                                                           int tiles_n) {
+    __shared__ float red[4][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const int ksteps = K >> 4;
+    const bf16_t* ap = A + (size_t)min(m0 + (lane & 31), M - 1) * lda + (lane >> 5) * 8;   // clamped rows: loads are unconditional
+    const bf16_t* bp = B + (size_t)min(n0 + (lane & 31), N - 1) * ldb + (lane >> 5) * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    constexpr int U = 8;
+    for (int ks = wave; ks < ksteps; ks += 4 * U) {
+        uint4 a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = min(ks + 4 * u, ksteps - 1);
+            a[u] = *reinterpret_cast<const uint4*>(ap + (size_t)k * 16);
+            b[u] = *reinterpret_cast<const uint4*>(bp + (size_t)k * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool in = ks + 4 * u < ksteps;   // (a select on the loaded value, not a branch around the load)
+            const uint4 av = in ? a[u] : make_uint4(0, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b[u]), acc, 0, 0, 0);
+        }
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[r];
+    __syncthreads();
+    const int row = tid >> 3, c0 = (tid & 7) * 4;
+    const int gr = m0 + row;
+    if (gr >= M) return;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = red[0][row][c0 + j] + red[1][row][c0 + j] + red[2][row][c0 + j] + red[3][row][c0 + j];
+    TO* cp = C + (size_t)gr * ldc + n0 + c0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gc = n0 + c0 + j;
+        if (gc < N) {
+            if (bias != nullptr) v[j] += bias[gc];
+            if (accumulate) v[j] += load_out<TO>(cp + j);
+        }
+    }
+    if (n0 + c0 + 3 < N && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+        if constexpr (sizeof(TO) == 2) {
+            uint2 pk;
+            pk.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            pk.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(cp) = pk;
+        } else {
+            *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + c0 + j < N) store_out<TO>(cp + j, v[j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // TN contraction: C[M,N] = sum_k A[k][m] * B[k][n]  with A [K, lda>=M] and B [K, ldb>=N] row-major (bf16).
 // This is the weight gradient dW = dh^T . x taken straight from the row-major activations: no transposed copies.
 // Tiles are staged in LDS exactly as they lie in memory ([k][m] rows of 256 B + 64 B pad, coalesced 16-byte loads);
@@ -1000,16 +1080,14 @@ constexpr int TWM = 256;              // tile rows (m)
 constexpr int TWROWA = TWM * 2 + 64;  // LDS bytes per k row of the A tile: 576 = 64 mod 256, the four k rows of a read group land in disjoint banks
 
 template <typename TO>
-__global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
-                                                           float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc,
-                                                           int k_per_split, int accumulate, int tiles_n, int tiles_mn, int nsplit) {
+__device__ __forceinline__ void tn_wide_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
+                                             float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc,
+                                             int k_per_split, int accumulate, int tiles_n, int tile, int split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];  // max(A + B tiles = 57 344 B, epilogue 8 x 9 216 B)
     unsigned char* sA = tw_smem;
     unsigned char* sB = tw_smem + TBK * TWROWA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);  // whole K-slices per XCD (see gemm_tn_kernel)
-    const int split = lin / tiles_mn, tile = lin % tiles_mn;
     const int m0 = (tile / tiles_n) * TWM, n0 = (tile % tiles_n) * BN;
     const int kbeg = split * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
@@ -1090,6 +1168,29 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
         if (k0 + 2 * TBK < kend) step(k0 + 2 * TBK, r2);
     }
     store_acc_tile<TO>(acc, tw_smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr, nullptr, 0, 0, wm * 64, wn * 64);
+}
+
+template <typename TO>
+__global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
+                                                           float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc,
+                                                           int k_per_split, int accumulate, int tiles_n, int tiles_mn, int nsplit) {
+    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);  // whole K-slices per XCD (see gemm_tn_kernel)
+    tn_wide_body<TO>(A, B, C, ws, M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, lin % tiles_mn, lin / tiles_mn);
+}
+
+// the batched launch on the 256 x 128 tile: every problem's M a multiple of 256, N of 128 (the encoder layers' 768 x 512 / 512 x 768
+// weight gradients: 12 tiles each).  The batched 128 x 128 kernel moves 2.45 GB through the L2 -> LDS path for the six 33 280-row
+// gradients of a step (144 us at the ~17 TB/s that path sustains chip-wide, against 75 us of MFMA issue); this tile moves 1.84 GB.
+// tb.first_tile / tiles_n count WIDE tiles here.
+__global__ __launch_bounds__(512) void gemm_tn_batch_wide_kernel(TnBatch tb, float* __restrict__ ws, int K, int k_per_split, int nsplit) {
+    const int total = tb.first_tile[tb.nprob];
+    const int lin = xcd_remap(blockIdx.x, total * nsplit);
+    const int split = lin / total, t = lin % total;
+    int j = 0;
+    while (j + 1 < tb.nprob && t >= tb.first_tile[j + 1]) ++j;   // workgroup-uniform
+    const TnBatch::P& q = tb.p[j];
+    tn_wide_body<float>(q.A, q.B, q.C, ws + tb.ws_off[j], q.M, q.N, K, q.lda, q.ldb, q.ldc, k_per_split, 0, q.tiles_n,
+                        t - tb.first_tile[j], split);
 }
 
 #ifdef SPV_LAB   // measured slower inside the training step: kept for the lab build only
@@ -1402,6 +1503,19 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
     }
     float* ws = splits > 1 ? static_cast<float*>(workspace) : nullptr;
     dim3 grid(tiles_m * tiles_n * splits);
+    if constexpr (sizeof(T) == 2) {
+        static const bool no_rows = SPV_LAB_SET("SPV_GEMM_NO_ROWS");   // A/B switch
+        // few rows: one 32 x 32 tile per workgroup straight from the L2-resident operands (no split-K workspace, no reduce launch)
+        if (!no_rows && splits == 1 && M <= 2048 && rg == 0 && bias2d == nullptr && bc == nullptr && t_drop_p == 0.0f && K % 16 == 0 && lda % 8 == 0 &&
+            ldb % 8 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && cdiv(M, 32) * cdiv(N, 32) >= 64) {
+            const int tn32 = cdiv(N, 32);
+            hipLaunchKernelGGL((gemm_nt_rows_kernel<TO>), dim3(cdiv(M, 32) * tn32), dim3(256), 0, st, static_cast<const bf16_t*>(A),
+                               static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), M, N, K, lda, ldb, ldc, accumulate, tn32);
+            SPV_LAUNCH_CHECK("spv_gemm_nt(rows)");
+            SPV_COUNT_PATH(SPV_PATH_GEMM_ROWS);
+            return 0;
+        }
+    }
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
         int mb, nstrips, groups, base, rem;
         const bool bc_ok = bc == nullptr || (bc_bf && !accumulate && bc_pw >= 8 && N % bc_pw == 0);   // (8 columns span <= 2 windows)
@@ -1733,10 +1847,28 @@ static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int
     }
     tb.first_tile[nprob] = tiles;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // the 256 x 128 tile when every problem divides into it and the K-slices are long enough to pay for its longer prologue
+    static const int wide_env = SPV_LAB_INT("SPV_TNB_WIDE", 1);
+    bool wide = wide_env != 0 && k_per_split >= 8 * TBK;
+    for (int i = 0; i < nprob && wide; ++i) wide = probs[i].m % TWM == 0 && probs[i].n % BN == 0;
     if (parts & 1) {
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN);
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN_BATCH);
-        hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+        if (wide) {
+            TnBatch tw = tb;
+            int wt = 0;
+            for (int i = 0; i < nprob; ++i) {
+                tw.first_tile[i] = wt;
+                wt += (probs[i].m / TWM) * cdiv(probs[i].n, BN);
+            }
+            tw.first_tile[nprob] = wt;
+            constexpr int WSMEM = 8 * 9216;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_batch_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WSMEM);
+            hipLaunchKernelGGL(gemm_tn_batch_wide_kernel, dim3(wt * splits), dim3(512), WSMEM, st, tw, static_cast<float*>(workspace), K, k_per_split, splits);
+            SPV_COUNT_PATH(SPV_PATH_GEMM_TN_WIDE);
+        } else {
+            hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+        }
         SPV_LAUNCH_CHECK("spv_gemm_tn_batch");
     }
     if (parts & 2) {

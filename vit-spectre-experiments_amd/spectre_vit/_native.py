@@ -20,7 +20,7 @@ c_vp, c_i, c_i64, c_u64, c_f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ct
 
 # indices of include/spv.h's SPV_PATH_* enum (dispatch census, test aid)
 PATH = dict(gemm_strip=0, gemm_strip_acc=1, gemm_tn=2, tail_lc=3, tail_up=4, tail_ln=5, fnet_mfma=6, gather_lds=7, gemm_tn_dma=8, gemm_tn_wide=9,
-            gemm_tn_batch=10, gemm_strip_pool=11, permut_row0=12)
+            gemm_tn_batch=10, gemm_strip_pool=11, permut_row0=12, gemm_rows=13)
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/spv.h one to one
 SIGNATURES = {

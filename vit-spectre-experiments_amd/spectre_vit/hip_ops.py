@@ -372,7 +372,10 @@ def _gemm(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspa
         # a handful of output tiles (the 512 x 100 classifier head: 4) would run on a handful of CUs for the whole K
         # loop -- 42 us for 52 MFLOP in fp32; split the reduction so that ~256 workgroups share it
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        if tiles <= 32:
+        # (bf16 problems of few rows take the library's 32 x 32-tile kernel instead: no workspace, no reduce launch)
+        rows_kernel = (a.dtype == torch.bfloat16 and M <= 2048 and K % 16 == 0 and lda % 8 == 0 and ldb % 8 == 0
+                       and ((M + 31) // 32) * ((N + 31) // 32) >= 64)
+        if tiles <= 32 and not rows_kernel:
             splits = max(1, min(K // 64, 256 // tiles))
             if splits > 1:
                 workspace = torch.empty((splits * M * N,), dtype=torch.float32, device=c.device)
@@ -475,6 +478,11 @@ def _batch_splits(tiles):
     4-wave workgroups per CU) best; measured on 192 tiles: 5 slices (960 workgroups) 307 us, 2: 321, 4: 355, 3: 396"""
     if _WGRAD_SPLITS > 0:
         return _WGRAD_SPLITS
+    if 160 <= tiles <= 224:
+        # the six 33 280-row layer gradients of the Small model (192 tiles): re-measured in round 3 on both tile shapes of the batched
+        # kernel (tools/tnb_bench.py: 3: 296 / 278 us, 4: 305 / 341, 5: 259 / 281, 6: 247 / 249, 7: 231 / 229, 8: 256 / 267, 10: 242 / 240)
+        # and inside the replayed step (5 -> 7 slices: 1.734 / 1.719 -> 1.702 / 1.712 ms)
+        return 7
     best, best_score = 1, -1.0
     for sp in range(1, 11):
         rounds = tiles * sp / 512.0
