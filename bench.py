@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--dp-graph", action="store_true", help="N GPUs, permut mixer: use the two-graph rank step as well (default: eager, overlapped)")
     ap.add_argument("--no-dp-sequence", action="store_true", help="skip the dp_sequence leg of the single-GPU line")
     ap.add_argument("--no-script-leg", action="store_true", help="skip the as_script leg (the reference loop verbatim) of the single-GPU line")
+    ap.add_argument("--no-base224", action="store_true", help="skip the Base/224 student leg (BASELINE config 5, one GPU) of the default single-GPU line")
     ap.add_argument("--no-every-row", action="store_true",
                     help="skip the second graph-replayed measurement with the last layer's feed-forward half over every row (profiling runs)")
     return ap.parse_args(argv)
@@ -116,9 +117,56 @@ def cpu_baseline(mixer, batch, steps):
         st.step(img, labels, cfg["num_encoders"], cfg["patch_size"], mixer_cpu)
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
-    return dict(value=round(batch / dt, 2), unit="images/sec", cores=threads, kind="port",
-                sample=f"torch-CPU port of the reference step (stock ATen ops + autograd + AdamW, fp32, {mixer_cpu} mixer, dropout 0): "
-                       f"1 warm-up + {len(times)} timed steps of bs {batch}, median {dt:.2f} s/step, {threads} threads of {cores} host cores")
+    rec = dict(value=round(batch / dt, 2), unit="images/sec", cores=threads, kind="port",
+               sample=f"torch-CPU port of the reference step (stock ATen ops + autograd + AdamW, fp32, {mixer_cpu} mixer, dropout 0): "
+                      f"1 warm-up + {len(times)} timed steps of bs {batch}, median {dt:.2f} s/step, {threads} threads of {cores} host cores")
+    if threads != 8 and cores >= 8 and steps > 0:
+        # one run at n = 8 as well, for comparability with the survey's measurement of the reference itself
+        # (25 img/s on 8 vCPUs, MHPermutMix); one timed step
+        torch.set_num_threads(8)
+        st.step(img, labels, cfg["num_encoders"], cfg["patch_size"], mixer_cpu)
+        t0 = time.perf_counter()
+        st.step(img, labels, cfg["num_encoders"], cfg["patch_size"], mixer_cpu)
+        d8 = time.perf_counter() - t0
+        rec["at_8_threads"] = dict(value=round(batch / d8, 2), unit="images/sec", cores=8, sample=f"1 warm-up + 1 timed step, {d8:.2f} s/step")
+        torch.set_num_threads(threads)
+    return rec
+
+
+def base224_leg(dev, steps=5, warmup=2, batch=64):
+    """BASELINE config 5, student side, on one GPU: Spectre-ViT-Base (the reference's SpectreViT defaults, spectre.py:162-171: E 768,
+    12 layers, 12 heads, F 3072, dropout 0.1, HEAD mixer) at 224 / 16 -> 197 tokens, train step fwd + CE + bwd + AdamW in bf16, replayed
+    from one HIP graph.  (The distillation loop adds a frozen teacher forward and the KD loss, train.py:298-361; the teacher is not
+    available offline -- SURVEY 8c -- so the student step is what can be measured.)"""
+    import torch
+    from spectre_vit.graph import GraphedTrainStep
+    from spectre_vit.loss import CrossEntropyLoss
+    from spectre_vit.models.spectre.spectre import SpectreViT
+    from spectre_vit.optim import FusedAdamW
+    torch.manual_seed(0)
+    m = SpectreViT(img_size=224, patch_size=16, in_channels=3, num_classes=100, embed_dim=768, num_encoders=12, num_heads=12,
+                   hidden_dim=3072, dropout=0.1, mixer="permut").to(dev).train()
+    img = torch.randn(batch, 3, 224, 224, device=dev)
+    lab = torch.randint(0, 100, (batch,), device=dev)
+    opt = FusedAdamW(m.parameters(), lr=1e-4, weight_decay=0.01, capturable=True, static_grads=True)
+    step = GraphedTrainStep(m, opt, CrossEntropyLoss(), img, lab, autocast_dtype=torch.bfloat16, warmup=2)
+    try:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out = dict(value=round(batch / dt, 1), unit="images/sec", ms_per_step=round(dt * 1e3, 2), steps=steps, batch=batch, launch="graph",
+                   workload="Spectre-ViT-Base student (E768 H12 F3072 L12, 224/16 -> 197 tokens, MHPermutMix), train step fwd+CE+bwd+AdamW, bf16",
+                   final_loss=round(float(loss.item()), 4), parameters=sum(p.numel() for p in m.parameters()))
+    finally:
+        step.close()
+    del step, opt, m
+    torch.cuda.empty_cache()
+    return out
 
 
 def attach_pmc_traffic(roof, mixer):
@@ -132,7 +180,8 @@ def attach_pmc_traffic(roof, mixer):
     if not files:
         return
     data = json.load(open(files[-1]))
-    pats = {"gemm": ("gemm_nt_strip", "gemm_nt_kernel", "gemm_nt_glds"), "gemm_acc": ("gemm_nt_strip", "gemm_nt_kernel"), "gemm_tn": ("gemm_tn", "wgrad"),
+    pats = {"gemm_tn_batch": ("gemm_tn_batch_wide", "gemm_tn_batch"), "splitk_reduce_batch": ("splitk_reduce_batch",),
+            "gemm": ("gemm_nt_strip", "gemm_nt_kernel", "gemm_nt_glds"), "gemm_acc": ("gemm_nt_strip", "gemm_nt_kernel"), "gemm_tn": ("gemm_tn", "wgrad"),
             "gemm_pool_bwd": ("gemm_nt_strip", "gemm_nt_pool", "gemm_nt_kernel"), "fnet_ln_fwd": ("fnet",), "fnet_ln_bwd": ("fnet",),
             "fnet_mix": ("fnet",), "tail_fwd": ("tail_fwd",), "tail_bwd": ("tail_bwd",), "tail_bwd_up": ("tail_bwd",),
             "tail_ln_fwd": ("tail_fwd",), "tail_ln_bwd": ("tail_bwd",), "gather_fwd": ("gather_fwd",), "gather_bwd": ("gather_bwd",)}
@@ -515,6 +564,8 @@ def main():
             rec["dp_sequence"]["collective"] = "torch.distributed all_reduce in a one-rank RCCL group" if fc else "skipped (no process group)"
         if not args.no_script_leg:
             rec["as_script"] = script_leg(args, args.mixer, dev, vsteps, vwarm)
+        if not args.no_base224 and args.mixer == "fft" and args.batch == 512:
+            rec["base224_student"] = base224_leg(dev)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.mixer, args.batch, args.cpu_steps)

@@ -69,7 +69,7 @@ def test_gemm_nt(ops, dtype, M, N, K, splits):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("M,N,K", [(512, 768, 512), (512, 512, 768), (500, 776, 528), (2048, 264, 16), (33, 2048, 1040), (512, 512, 48)])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 512), (512, 512, 768), (500, 776, 528), (2048, 264, 16), (33, 2048, 1040), (512, 512, 48), (96, 1024, 1536)])
 def test_gemm_nt_rows_kernel(ops, M, N, K, out_dtype):
     """The few-rows kernel (bf16 operands, M <= 2048, one 32 x 32 tile per workgroup, K dealt over four waves; the CLS-only last layer's
     512-row GEMMs) against fp64: ragged M and N, a K that is not a multiple of the per-wave batch, bias, accumulate, both output types;

@@ -22,7 +22,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_pass(counter, outdir, mixer):
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "--", sys.executable,
-           os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-every-row", "--variants", "none", "--mixer", mixer]
+           os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline", "--no-every-row", "--no-dp-sequence", "--no-script-leg", "--no-base224",
+           "--variants", "none", "--mixer", mixer]
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     f = glob.glob(os.path.join(outdir, "*", "*counter_collection.csv"))[0]

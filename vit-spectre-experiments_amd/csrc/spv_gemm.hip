@@ -941,13 +941,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
 template <typename TO, int DEPTH>
 __device__ __forceinline__ void tn_tile_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
                                              float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc, int k_per_split,
-                                             int accumulate, int tiles_n, int tile, int split) {
+                                             int accumulate, int tiles_n, int tile, int split, int tiles_m = 0) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TBK * TROWB];  // 40 960 B (>= the epilogue's 36 864 B)
     unsigned char* sA = smem;
     unsigned char* sB = smem + TBK * TROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    // tile order.  Few column tiles (the layer gradients, 6 x 4): row-major.  Many more column tiles than row tiles (the MHPermutMix
+    // gradient [512, 8192, 33280]: 4 x 64): the row tiles of one column are NEIGHBOURS, so the four workgroups that read the same
+    // 8.5 MB panel of the gathered matrix run on one XCD at the same time and three of them hit in its L2 -- row-major put them 64 tiles
+    // apart, i.e. on different XCDs, and the 545 MB matrix was fetched once per row tile (PMC: 2.25 GB per launch against 0.6 GB).
+    const bool m_fast = tiles_m > 0 && tiles_n >= 4 * tiles_m;
+    const int tm = m_fast ? tile % tiles_m : tile / tiles_n, tn = m_fast ? tile / tiles_m : tile % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = split * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
@@ -1040,7 +1045,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     // share a slice's operand rows hit in that XCD's L2 (per-slice round-robin made every XCD fetch every slice:
     // 3.4x the algorithmic HBM reads on the weight-gradient GEMM, FETCH_SIZE)
     const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);
-    tn_tile_body<TO, DEPTH>(A, B, C, ws, M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, lin % tiles_mn, lin / tiles_mn);
+    tn_tile_body<TO, DEPTH>(A, B, C, ws, M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, lin % tiles_mn, lin / tiles_mn, tiles_mn / tiles_n);
 }
 
 // Several weight gradients with the same K (the rows of the batch) in ONE launch: the layer weight gradients are 24 tiles each, so
@@ -1506,8 +1511,11 @@ int launch_gemm(const void* A, const void* B, const float* bias, void* C, int M,
     if constexpr (sizeof(T) == 2) {
         static const bool no_rows = SPV_LAB_SET("SPV_GEMM_NO_ROWS");   // A/B switch
         // few rows: one 32 x 32 tile per workgroup straight from the L2-resident operands (no split-K workspace, no reduce launch)
-        if (!no_rows && splits == 1 && M <= 2048 && rg == 0 && bias2d == nullptr && bc == nullptr && t_drop_p == 0.0f && K % 16 == 0 && lda % 8 == 0 &&
-            ldb % 8 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 && cdiv(M, 32) * cdiv(N, 32) >= 64) {
+        // (K <= 1536: a wave walks its K share in batches of 8 k-steps, one L2 round trip each -- at K = 8192 that chain is 40 us against
+        // 15 + 5 for split-K + reduce; <= 1024 tiles: beyond that the 32 x 32 tiles re-read the operands 4x as often as 128 x 128 ones)
+        if (!no_rows && splits == 1 && M <= 2048 && K <= 1536 && rg == 0 && bias2d == nullptr && bc == nullptr && t_drop_p == 0.0f && K % 16 == 0 &&
+            lda % 8 == 0 && ldb % 8 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0 &&
+            cdiv(M, 32) * cdiv(N, 32) >= 64 && cdiv(M, 32) * cdiv(N, 32) <= 1024) {
             const int tn32 = cdiv(N, 32);
             hipLaunchKernelGGL((gemm_nt_rows_kernel<TO>), dim3(cdiv(M, 32) * tn32), dim3(256), 0, st, static_cast<const bf16_t*>(A),
                                static_cast<const bf16_t*>(B), bias, static_cast<TO*>(C), M, N, K, lda, ldb, ldc, accumulate, tn32);

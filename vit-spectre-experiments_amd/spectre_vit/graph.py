@@ -180,12 +180,17 @@ class GraphedDPStep(GraphedTrainStep):
 
     def _build(self, warmup):
         self._warm(warmup)
+        torch.cuda.synchronize()   # the warm-up's collectives are complete before a capture begins
         pool = torch.cuda.graph_pool_handle()
+        # capture_error_mode "thread_local": only THIS thread's calls are checked against the capture.  A process group keeps a
+        # watchdog thread that queries its work events at any time; under the default ("global") mode such a query from another
+        # thread can invalidate an ongoing capture.  Nothing of the collective is captured here, so thread-local checking is exact.
+        mode = dict(capture_error_mode="thread_local")
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, pool=pool), self._hold():
+        with torch.cuda.graph(self.graph, pool=pool, **mode), self._hold():
             self.loss, self.out = self._forward_backward()
         self.graph_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_opt, pool=pool):
+        with torch.cuda.graph(self.graph_opt, pool=pool, **mode):
             self.optimizer.step()
 
     def _replay(self):

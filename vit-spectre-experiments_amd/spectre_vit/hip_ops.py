@@ -373,8 +373,8 @@ def _gemm(a, b, bias, c, M, N, K, lda, ldb, ldc, accumulate=0, splits=1, workspa
         # loop -- 42 us for 52 MFLOP in fp32; split the reduction so that ~256 workgroups share it
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         # (bf16 problems of few rows take the library's 32 x 32-tile kernel instead: no workspace, no reduce launch)
-        rows_kernel = (a.dtype == torch.bfloat16 and M <= 2048 and K % 16 == 0 and lda % 8 == 0 and ldb % 8 == 0
-                       and ((M + 31) // 32) * ((N + 31) // 32) >= 64)
+        rows_kernel = (a.dtype == torch.bfloat16 and M <= 2048 and K <= 1536 and K % 16 == 0 and lda % 8 == 0 and ldb % 8 == 0
+                       and 64 <= ((M + 31) // 32) * ((N + 31) // 32) <= 1024)
         if tiles <= 32 and not rows_kernel:
             splits = max(1, min(K // 64, 256 // tiles))
             if splits > 1:
