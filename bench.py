@@ -436,7 +436,29 @@ def main():
         if not stand_in:
             torch.cuda.synchronize()
 
-    job = Job(args, args.mixer, dev, rank, launch=launch, stand_in=stand_in, force_collective=force_collective)
+    job, build_error = None, None
+    try:
+        job = Job(args, args.mixer, dev, rank, launch=launch, stand_in=stand_in, force_collective=force_collective)
+    except Exception as exc:   # noqa: BLE001 -- reported in the line; only the multi-rank graph step has a fallback
+        if not (world > 1 and launch == "dp_graph"):
+            raise
+        build_error = f"{type(exc).__name__}: {exc}"
+    if world > 1 and launch == "dp_graph":
+        # The two-graph rank step has never run over real xGMI links when this line is written (one GPU per development box): if its
+        # construction fails on ANY rank -- the capture next to a live RCCL communicator is the untested part -- EVERY rank falls back
+        # to the eager step with the overlapped bucket exchange, and the line says so.
+        ok = torch.tensor([0 if job is None else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if job is not None:
+                job.close()
+            job = None
+            torch.cuda.empty_cache()
+            launch = "eager"
+            if rank == 0:
+                sys.stderr.write(f"bench.py: GraphedDPStep could not be built on every rank ({build_error or 'another rank failed'}); "
+                                 "falling back to the eager data-parallel step\n")
+            job = Job(args, args.mixer, dev, rank, launch=launch, stand_in=stand_in)
     elapsed, loss = timed_region(job, sync, args.steps, args.warmup)
     final_loss = float(loss.item())
     # roofline pass: the SAME launch sequence as the timed region (in the graph modes: the captured sequence issued by the host, with the
@@ -503,6 +525,8 @@ def main():
                                          "all ranks on one device over gloo: control-flow check, not a measurement")} if rehearsal else {}),
                        "mixer": args.mixer if args.model == "spectre" else "attention", "global_batch": args.batch * world,
                        "parallelism": f"dp{world}", "launch": launch_text},
+            **({"dp_graph_fallback": build_error or "another rank failed to build the two-graph step"}
+               if (world > 1 and launch == "eager" and graphable and (args.mixer != "permut" or args.dp_graph)) else {}),
             "rccl_ranks": world if backend == "nccl" else (1 if force_collective else 0),
             "backend": backend or "none (single process)",
             "final_loss": round(final_loss, 4),

@@ -452,8 +452,14 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
     // load, then all compute, then all store -- HBM idle while the VALUs work and vice versa.  The second half of the
     // grid (the second workgroup of each CU under in-order dispatch; a performance assumption only) sleeps through the
     // first half's load phase, so its loads overlap their FFTs and its FFTs overlap their stores.
-    if (stagger > 0 && blockIdx.x >= (gridDim.x >> 1))
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    if (stagger > 0) {
+        // which workgroups wait: the second half of the grid (bit 8 clear), or -- bit 8 set -- the workgroups in an ODD threadgroup
+        // slot of their CU (HW_REG_HW_ID bits 19:16, TG_ID): with two resident workgroups per CU exactly one of each pair,
+        // whatever the dispatcher's block -> CU placement (a performance heuristic only: any outcome is correct)
+        const bool second = (stagger & 256) ? (__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1) != 0 : blockIdx.x >= (gridDim.x >> 1);
+        if (second)
+            for (int i = 0; i < (stagger & 255); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     V2_STAMP(0);
     // the DFT-matrix fragments of phase B: requested first, so that they arrive under the tile's own loads
     V3Tab tab;
@@ -1047,7 +1053,7 @@ extern "C" int spv_fnet_ln_supported(int tokens, int dim, int dtype) {
 }
 
 static int fnet_ln_stagger(int batch) {
-    static const int env = SPV_LAB_INT("SPV_FNET_LN_STAGGER", 0);  // x 8128 cycles; tuning aid
+    static const int env = SPV_LAB_INT("SPV_FNET_LN_STAGGER", 0);  // x 8128 cycles (+ 256: by threadgroup slot instead of grid half); tuning aid
     return batch >= 512 ? env : 0;
 }
 static size_t fnet_v2_lds(int tokens) { return (size_t)std::max(2 * ((tokens + 1) / 2), 2 * (tokens / 2 + 1)) * V2RS; }

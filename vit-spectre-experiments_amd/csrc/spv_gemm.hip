@@ -924,6 +924,9 @@ __global__ __launch_bounds__(256) void gemm_nt_rows_kernel(const bf16_t* __restr
 // transposing LDS read: per 16-lane group it reads a 4 (k) x 16 (m) block and hands lane i column i.  With the
 // 320-byte row stride the four k rows of a group land in four disjoint 16-bank ranges (conflict free).
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+#ifdef SPV_LAB
+__device__ int g_tn_ablate = 0;   // set by the host from SPV_TN_ABLATE before a launch (lab build only)
+#endif
 constexpr int TROWB = 256 + 64;  // LDS bytes per k row (128 bf16 + pad)
 constexpr int TBK = 64;          // k rows per stage (16 MFMAs per wave between barriers)
 
@@ -1013,11 +1016,16 @@ __device__ __forceinline__ void tn_tile_body(const bf16_t* __restrict__ A, const
         }
     };
     // one K-tile: its registers go to LDS, the set is refilled with the tile three ahead, then the MFMAs
+#ifdef SPV_LAB
+    const int abl = g_tn_ablate;   // lab: 1 = no LDS stores, 2 = no global loads after the prologue, 4 = no MFMAs / fragment reads (wrong results)
+#else
+    constexpr int abl = 0;
+#endif
     auto step = [&](int k0, RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
-        store_tile(ra, rb);
+        if (!(abl & 1)) store_tile(ra, rb);
         __syncthreads();
-        if (k0 + DEPTH * TBK < kend) load_tile(k0 + DEPTH * TBK, ra, rb);
-        multiply();
+        if (!(abl & 2) && k0 + DEPTH * TBK < kend) load_tile(k0 + DEPTH * TBK, ra, rb);
+        if (!(abl & 4)) multiply();
         __syncthreads();
     };
 
@@ -1029,6 +1037,21 @@ __device__ __forceinline__ void tn_tile_body(const bf16_t* __restrict__ A, const
             step(k0, ra0, rb0);
             if (k0 + TBK < kend) step(k0 + TBK, ra1, rb1);
             if (k0 + 2 * TBK < kend) step(k0 + 2 * TBK, ra2, rb2);
+        }
+    } else if constexpr (DEPTH == 5) {
+        // five K-tiles of operand rows in flight (160 staging VGPRs: one wave per SIMD and workgroup, two workgroups per CU): the
+        // batched launch, whose ablations put the exposed operand loads at a third of its time with three in flight
+        RegTile ra3, rb3, ra4, rb4;
+        if (kbeg + TBK < kend) load_tile(kbeg + TBK, ra1, rb1);
+        if (kbeg + 2 * TBK < kend) load_tile(kbeg + 2 * TBK, ra2, rb2);
+        if (kbeg + 3 * TBK < kend) load_tile(kbeg + 3 * TBK, ra3, rb3);
+        if (kbeg + 4 * TBK < kend) load_tile(kbeg + 4 * TBK, ra4, rb4);
+        for (int k0 = kbeg; k0 < kend; k0 += 5 * TBK) {
+            step(k0, ra0, rb0);
+            if (k0 + TBK < kend) step(k0 + TBK, ra1, rb1);
+            if (k0 + 2 * TBK < kend) step(k0 + 2 * TBK, ra2, rb2);
+            if (k0 + 3 * TBK < kend) step(k0 + 3 * TBK, ra3, rb3);
+            if (k0 + 4 * TBK < kend) step(k0 + 4 * TBK, ra4, rb4);
         }
     } else {
         for (int k0 = kbeg; k0 < kend; k0 += TBK) step(k0, ra0, rb0);
@@ -1064,6 +1087,7 @@ struct TnBatch {
         int M, N, lda, ldb, ldc, tiles_n;
     } p[TNB_MAX];
 };
+template <int DEPTH>
 __global__ __launch_bounds__(256) void gemm_tn_batch_kernel(TnBatch tb, float* __restrict__ ws, int K, int k_per_split, int nsplit) {
     const int total = tb.first_tile[tb.nprob];
     const int lin = xcd_remap(blockIdx.x, total * nsplit);
@@ -1071,8 +1095,8 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_kernel(TnBatch tb, float* _
     int j = 0;
     while (j + 1 < tb.nprob && t >= tb.first_tile[j + 1]) ++j;   // workgroup-uniform
     const TnBatch::P& q = tb.p[j];
-    tn_tile_body<float, 3>(q.A, q.B, q.C, ws + tb.ws_off[j], q.M, q.N, K, q.lda, q.ldb, q.ldc, k_per_split, 0, q.tiles_n,
-                           t - tb.first_tile[j], split);
+    tn_tile_body<float, DEPTH>(q.A, q.B, q.C, ws + tb.ws_off[j], q.M, q.N, K, q.lda, q.ldb, q.ldc, k_per_split, 0, q.tiles_n,
+                               t - tb.first_tile[j], split);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1855,6 +1879,12 @@ static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int
     }
     tb.first_tile[nprob] = tiles;
     hipStream_t st = static_cast<hipStream_t>(stream);
+#ifdef SPV_LAB
+    {
+        const int abl = SPV_LAB_INT("SPV_TN_ABLATE", 0);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tn_ablate), &abl, sizeof(abl));
+    }
+#endif
     // the 256 x 128 tile when every problem divides into it and the K-slices are long enough to pay for its longer prologue
     static const int wide_env = SPV_LAB_INT("SPV_TNB_WIDE", 1);
     bool wide = wide_env != 0 && k_per_split >= 8 * TBK;
@@ -1875,7 +1905,11 @@ static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int
             hipLaunchKernelGGL(gemm_tn_batch_wide_kernel, dim3(wt * splits), dim3(512), WSMEM, st, tw, static_cast<float*>(workspace), K, k_per_split, splits);
             SPV_COUNT_PATH(SPV_PATH_GEMM_TN_WIDE);
         } else {
-            hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+            static const int bdepth = SPV_LAB_INT("SPV_TNB_DEPTH", 3);
+            if (bdepth == 5 && k_per_split >= 10 * TBK)
+                hipLaunchKernelGGL(gemm_tn_batch_kernel<5>, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+            else
+                hipLaunchKernelGGL(gemm_tn_batch_kernel<3>, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
         }
         SPV_LAUNCH_CHECK("spv_gemm_tn_batch");
     }

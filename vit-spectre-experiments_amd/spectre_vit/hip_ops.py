@@ -454,7 +454,24 @@ HOLD_UNDER_DP = False
 TIME_HELD = False   # bench.py's roofline pass: bracket the launch sequence the headline times (held + batched weight gradients)
 
 
+# Two private torch entry points carry the held launches: the id of the running backward pass and the autograd engine's end-of-pass
+# callback.  Where a torch build lacks either, nothing is held (every launch runs at its own node: slower, same results).
+_task_id_fn = getattr(torch._C, "_current_graph_task_id", None)
+_engine = getattr(getattr(torch.autograd, "Variable", None), "_execution_engine", None)
+_HOLD_API = _task_id_fn is not None and hasattr(_engine, "queue_callback")
+
+
+def _graph_task_id():
+    return _task_id_fn() if _task_id_fn is not None else -1
+
+
+def _queue_end_of_backward(fn):
+    _engine.queue_callback(fn)
+
+
 def _hold_ok():
+    if not _HOLD_API:
+        return False
     if NO_HOLD or (_timing() and not TIME_HELD):
         return False
     if HOLD_UNDER_DP:
@@ -538,7 +555,7 @@ def start_held_wgrads():
     """Called by the LAST node of the backward pass that does real work (the patch embedding): every layer's weight gradient is held
     by now, so their batch starts here on the side stream and runs beside the embedding's backward -- a chain of small, latency-bound
     launches that leaves most of the chip idle.  The end-of-pass callback joins the streams.  True when something was started."""
-    if not (_WGRAD_SIDE and _held_wgrads and _held_task == torch._C._current_graph_task_id()) or _timing():
+    if not (_WGRAD_SIDE and _held_wgrads and _held_task == _graph_task_id()) or _timing():
         return False   # (a timed pass keeps the batch on the main stream: its event brackets must not overlap other kernels)
     side = _side_stream(_held_wgrads[0][0].device)
     side.wait_stream(torch.cuda.current_stream())
@@ -558,13 +575,13 @@ def _hold_wgrad(dh, x, dw, sink, rows, n, k, fold, fold_sunk):
     global _held_task
     if not (_WGRAD_HOLD and _hold_ok() and sink is not None and dw.data_ptr() == sink.view.data_ptr() and (fold is None or fold_sunk)):
         return False
-    task = torch._C._current_graph_task_id()
+    task = _graph_task_id()
     if task < 0:
         return False
     if _held_task != task:
         _held_folds.clear()
         _held_wgrads.clear()
-        torch.autograd.Variable._execution_engine.queue_callback(flush_held_folds)
+        _queue_end_of_backward(flush_held_folds)
         _held_task = task
     f = None if fold is None else (fold[0], tuple(o.data_ptr() for o in fold[1]), fold[2], fold[3])   # raw sink addresses, as _hold_fold
     _held_wgrads.append((dh, x, dw.data_ptr(), rows, n, k, f))
@@ -590,13 +607,13 @@ def _hold_fold(partials, outs, sinks, parts, n):
     global _held_task
     if not _hold_ok() or any(sk is None or o.data_ptr() != sk.view.data_ptr() for o, sk in zip(outs, sinks)):
         return False
-    task = torch._C._current_graph_task_id()
+    task = _graph_task_id()
     if task < 0:   # not inside a backward pass
         return False
     if _held_task != task:
         _held_folds.clear()   # leftovers of a backward pass that never finished (an exception): their launch must not ride along
         _held_wgrads.clear()
-        torch.autograd.Variable._execution_engine.queue_callback(flush_held_folds)
+        _queue_end_of_backward(flush_held_folds)
         _held_task = task
     _held_folds.append((partials, tuple(o.data_ptr() for o in outs), parts, n))
     return True
@@ -643,7 +660,7 @@ def _weight_grad(dh, x, rows, n, k, sink=None, fold=None, fold_sunk=False):
             if ws is None and splits > 1:
                 ws = torch.empty((splits * n * k,), dtype=torch.float32, device=dev)
             folds = [fold] if fold is not None else []
-            if riders and _held_task == torch._C._current_graph_task_id():
+            if riders and _held_task == _graph_task_id():
                 while _held_folds and len(folds) < FOLD_RIDERS:
                     folds.append(_held_folds.pop(0))
             if folds:
