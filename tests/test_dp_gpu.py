@@ -184,9 +184,12 @@ def test_graphed_dp_step_two_ranks_on_one_gpu(tmp_path):
     for k, g in ref["grads"].items():
         err = (r0["grads"][k] - g).abs().max().item() / (g.abs().max().item() + 1e-30)
         worst = max(worst, err)
-        # frozen weights: only the summation order over rows differs (fp32 re-association; the two 4-element spectral gates are
-        # projections of the 24 576-element embedding gradient with heavy cancellation, see test_gpu_bench_shapes.py)
-        if err >= (2e-3 if g.numel() <= 16 else 5e-5):
+        # frozen weights: the summation order over rows differs, and a 64-image shard may take another kernel than the 128-image
+        # batch for the same layer (the CLS-only last layer's 64-row GEMMs: split-K tiles, 128 rows: the few-rows kernel) -- other
+        # K orders flip a few bf16 roundings of the activations, which shows as ~2e-4 of the largest gradient entry (3.7e-7 when both
+        # sides take the same kernels).  A wrong exchange -- a missing 1 / world, a stale or unsummed slot -- is an O(1) error.  (The
+        # two 4-element spectral gates are projections of the embedding gradient with heavy cancellation, test_gpu_bench_shapes.py.)
+        if err >= (4e-3 if g.numel() <= 16 else 1e-3):
             failures.append(("grad " + k, err))
         # weights after the warm-up step + three replays: the difference is a small fraction of the distance travelled (bf16
         # re-rounding noise of the intermediate gradients, ~1e-3 of them)

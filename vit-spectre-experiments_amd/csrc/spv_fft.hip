@@ -483,10 +483,13 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int row = min(wave + 8 * (i0 + i), N - 1);  // rows past N: a valid address, the value is not used
-                dvv[i] = *reinterpret_cast<const uint4*>(x + base + (size_t)row * V2D + ch * 8);
-                mvv[i] = *reinterpret_cast<const uint4*>(ln.m_in + base + (size_t)row * V2D + ch * 8);
-                mn[i] = ln.mean[(size_t)blockIdx.x * N + row];
-                rs[i] = ln.rstd[(size_t)blockIdx.x * N + row];
+                // (uniform sample base + a 32-bit lane offset: the 64-bit per-lane address arithmetic of `ptr + base + row * V2D` was
+                // ~130 of the kernel's ~2 200 instructions, and the kernel is instruction-issue bound)
+                const unsigned off = (unsigned)row * V2D + (unsigned)ch * 8;
+                dvv[i] = *reinterpret_cast<const uint4*>(x + base + off);
+                mvv[i] = *reinterpret_cast<const uint4*>(ln.m_in + base + off);
+                mn[i] = (ln.mean + (size_t)blockIdx.x * N)[(unsigned)row];
+                rs[i] = (ln.rstd + (size_t)blockIdx.x * N)[(unsigned)row];
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < V2IT; ++i) {
             const int row = min(wave + 8 * i, N - 1);  // rows past N: a valid address, the value is not stored
-            xv[i] = *reinterpret_cast<const uint4*>(x + base + (size_t)row * V2D + ch * 8);
+            xv[i] = *reinterpret_cast<const uint4*>(x + base + ((unsigned)row * V2D + (unsigned)ch * 8));
         }
 #pragma unroll
         for (int i = 0; i < V2IT; ++i) {
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < V2IT; ++i) {
             const int r = min(wave_d + 8 * i, N - 1);
-            rv[i] = *reinterpret_cast<const uint4*>(resp + base_d + (size_t)r * V2D + ch_d * 8);
+            rv[i] = *reinterpret_cast<const uint4*>(resp + base_d + ((unsigned)r * V2D + (unsigned)ch_d * 8));
         }
     }
     float gg[8], bb[8];
@@ -695,21 +698,23 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
                 const float a1 = __uint_as_float(fw[u] & 0xffff0000u) + mf[2 * u + 1];
                 o[u] = pack_bf16x2(a0, a1);
             }
-            *reinterpret_cast<uint4*>(ln.prenorm + base_d + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4*>(ln.prenorm + base_d + ((unsigned)r * V2D + (unsigned)k0)) = make_uint4(o[0], o[1], o[2], o[3]);
             float v[8];
-            float sm = 0.0f;
+            // one pass: sum and sum of squares reduced side by side (two independent DPP chains fill each other's hazard slots; the
+            // centred second pass cost 8 subtractions and a second, dependent reduction per row).  var = E[v^2] - mean^2 in fp32 on
+            // bf16-rounded values of a zero-mean-ish spectrum: the cancellation is far below the bf16 resolution of the output
+            float sm = 0.0f, sq = 0.0f;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[2 * u] = __uint_as_float(o[u] << 16);
                 v[2 * u + 1] = __uint_as_float(o[u] & 0xffff0000u);
                 sm += v[2 * u] + v[2 * u + 1];
+                sq = fmaf(v[2 * u], v[2 * u], sq);
+                sq = fmaf(v[2 * u + 1], v[2 * u + 1], sq);
             }
             const float mean = wave_sum(sm) * (1.0f / V2D);
-            float sq = 0.0f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const float d = v[u] - mean; sq += d * d; }
-            const float rstd = rsqrtf(wave_sum(sq) * (1.0f / V2D) + V2_LN_EPS);
-            if (lane == 0) { ln.mean[(size_t)blockIdx.x * N + r] = mean; ln.rstd[(size_t)blockIdx.x * N + r] = rstd; }
+            const float rstd = rsqrtf(fmaxf(wave_sum(sq) * (1.0f / V2D) - mean * mean, 0.0f) + V2_LN_EPS);
+            if (lane == 0) { (ln.mean + (size_t)blockIdx.x * N)[(unsigned)r] = mean; (ln.rstd + (size_t)blockIdx.x * N)[(unsigned)r] = rstd; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float e0 = (v[2 * u] - mean) * rstd * gg[2 * u] + bb[2 * u] + __uint_as_float(aw[u] << 16);
@@ -724,7 +729,7 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
                 o[u] = pack_bf16x2(a0, a1);
             }
         }
-        *reinterpret_cast<uint4*>(y + base_d + (size_t)r * V2D + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<uint4*>(y + base_d + ((unsigned)r * V2D + (unsigned)k0)) = make_uint4(o[0], o[1], o[2], o[3]);
     }
     V2_STAMP(9);
     V2_STAMP_RT(11);
