@@ -700,20 +700,18 @@ __global__ __launch_bounds__(512, 4) void fnet_mfma_kernel(const bf16_t* __restr
             }
             *reinterpret_cast<uint4*>(ln.prenorm + base_d + ((unsigned)r * V2D + (unsigned)k0)) = make_uint4(o[0], o[1], o[2], o[3]);
             float v[8];
-            // one pass: sum and sum of squares reduced side by side (two independent DPP chains fill each other's hazard slots; the
-            // centred second pass cost 8 subtractions and a second, dependent reduction per row).  var = E[v^2] - mean^2 in fp32 on
-            // bf16-rounded values of a zero-mean-ish spectrum: the cancellation is far below the bf16 resolution of the output
-            float sm = 0.0f, sq = 0.0f;
+            float sm = 0.0f;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[2 * u] = __uint_as_float(o[u] << 16);
                 v[2 * u + 1] = __uint_as_float(o[u] & 0xffff0000u);
                 sm += v[2 * u] + v[2 * u + 1];
-                sq = fmaf(v[2 * u], v[2 * u], sq);
-                sq = fmaf(v[2 * u + 1], v[2 * u + 1], sq);
             }
             const float mean = wave_sum(sm) * (1.0f / V2D);
-            const float rstd = rsqrtf(fmaxf(wave_sum(sq) * (1.0f / V2D) - mean * mean, 0.0f) + V2_LN_EPS);
+            float sq = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float d = v[u] - mean; sq += d * d; }
+            const float rstd = rsqrtf(wave_sum(sq) * (1.0f / V2D) + V2_LN_EPS);
             if (lane == 0) { (ln.mean + (size_t)blockIdx.x * N)[(unsigned)r] = mean; (ln.rstd + (size_t)blockIdx.x * N)[(unsigned)r] = rstd; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
