@@ -482,3 +482,25 @@ def test_side_stream_batch_with_a_fresh_allocator(in_graph):
         ref = single[k]
         err = (batched[k] - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
         assert err <= 2e-5, (k, err)   # other K-slices: the same sums to fp32 re-association; a clobbered partial would be O(1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("uint8_input", [False, True])
+def test_harness_graph_mode_follows_the_eager_loop(tmp_path, uint8_input):
+    """harness.train(graph=True): the same run with the step replayed from a HIP graph and the one-launch AdamW -- loss curve,
+    accuracies and checkpoint as the eager loop produces them (same seeds and batches; the first step of the graph run is the
+    warm-up step, a real training step).  The two runs differ by the optimizer kernel (2e-6 parity) and the batched weight
+    gradients (fp32 re-association): bf16 re-rounding turns that into ~1e-3 on the epoch loss."""
+    from spectre_vit.harness import train
+    cfg = "spectre_vit/configs/spectre_vit_mnist.py"
+    kw = dict(mixer="fft", epochs=2, steps_per_epoch=10, batch_size=64, n_train=1024, n_val=256, log=lambda r: None, uint8_input=uint8_input)
+    _, h_eager = train(cfg, out_dir=str(tmp_path / "e"), **kw)
+    _, h_graph = train(cfg, out_dir=str(tmp_path / "g"), graph=True, **kw)
+    for a, b in zip(h_eager, h_graph):
+        assert a["steps"] == b["steps"] == 10
+        assert abs(a["Loss/Train"] - b["Loss/Train"]) < 1e-2 * abs(a["Loss/Train"]), (a, b)
+        assert abs(a["Loss/Validation"] - b["Loss/Validation"]) < 2e-2 * abs(a["Loss/Validation"]), (a, b)
+    assert h_graph[-1]["Loss/Train"] < h_graph[0]["Loss/Train"]
+    assert os.path.exists(os.path.join(tmp_path, "g", "model_best.pt"))
+    with pytest.raises(ValueError, match="distillation"):
+        train(cfg, graph=True, distill=True, out_dir=str(tmp_path / "x"), **kw)

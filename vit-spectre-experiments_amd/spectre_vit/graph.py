@@ -125,8 +125,11 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), self._hold():
             for _ in range(warmup):
-                self._eager_step()
+                loss, out = self._eager_step()
         torch.cuda.current_stream().wait_stream(side)
+        # the warm-up steps are REAL training steps on the example batch: a caller that feeds the example batch as its first batch
+        # takes the last one's results from here instead of replaying that batch a second time
+        self.warm_loss, self.warm_out = loss.detach(), out.detach()
         hip_ops._shadows = type(hip_ops._shadows)()  # the weight casts must be recorded in the graph, not served from a cache
 
     def _build(self, warmup):

@@ -80,7 +80,11 @@ class SyntheticCifar:
 
 
 def train(config_path, mixer="permut", epochs=1, steps_per_epoch=None, batch_size=None, n_train=4096, n_val=1024,
-          use_amp=True, distill=False, out_dir="runs/spectre_vit", log=print, uint8_input=False):
+          use_amp=True, distill=False, out_dir="runs/spectre_vit", log=print, uint8_input=False, graph=False):
+    """graph=True (not with distill): the training step -- zero_grad, forward, loss, backward, AdamW -- is replayed from HIP graphs
+    (spectre_vit.graph: one graph in a single process; as a rank of a torch.distributed job two graphs around ONE all-reduce of the
+    flat gradient buffer) with the one-launch optimizer (spectre_vit.optim.FusedAdamW: torch.optim.AdamW's rule and state layout).
+    The default is the reference's own loop shape (train.py:216-238) with the overlapped bucket exchange under data parallelism."""
     c = parse_config(config_path)
     seed = getattr(c, "random_seed", 42)
     lr = getattr(c, "learning_rate", 1e-3)
@@ -99,8 +103,17 @@ def train(config_path, mixer="permut", epochs=1, steps_per_epoch=None, batch_siz
     train_set = SyntheticCifar(n_train, c, device, seed=seed)
     val_set = SyntheticCifar(n_val, c, device, seed=seed + 1)
     criterion = CrossEntropyLoss()  # nn.CrossEntropyLoss() of train.py:196 on the HIP path (spectre_vit/loss.py)
-    optimizer = optim.AdamW(model.parameters(), betas=c.adam_betas, lr=lr, weight_decay=c.adam_weight_decay)  # train.py:199-201
-    reducer = GradReducer(model)
+    if graph and distill:
+        raise ValueError("graph=True replays the plain training step; the distillation step (teacher forward + KD loss) runs eagerly")
+    gstep = None
+    if graph:
+        from spectre_vit.optim import FusedAdamW
+        optimizer = FusedAdamW(model.parameters(), betas=c.adam_betas, lr=lr, weight_decay=c.adam_weight_decay, capturable=True,
+                               static_grads=True)
+        reducer = None   # the graphed step owns its own (fixed-address) gradient buffer
+    else:
+        optimizer = optim.AdamW(model.parameters(), betas=c.adam_betas, lr=lr, weight_decay=c.adam_weight_decay)  # train.py:199-201
+        reducer = GradReducer(model)
     teacher = SyntheticTeacher(c.num_classes, 384, c.in_channels).to(device) if distill else None
     os.makedirs(out_dir, exist_ok=True)
     log_f = open(os.path.join(out_dir, "scalars.jsonl"), "a") if rank == 0 else None
@@ -113,6 +126,22 @@ def train(config_path, mixer="permut", epochs=1, steps_per_epoch=None, batch_siz
         correct = torch.zeros((), device=device, dtype=torch.int64)
         total, steps = 0, 0
         for img, label in train_set.batches(batch_size, True, gen, rank, world, raw_uint8=uint8_input and not distill):
+            if graph:
+                if gstep is None:   # built on the first batch (its shape is the captured one); warm-up steps are real training steps
+                    from spectre_vit.graph import GraphedDPStep, GraphedTrainStep
+                    cls = GraphedDPStep if world > 1 else GraphedTrainStep
+                    gstep = cls(model, optimizer, criterion, img, label.long(), autocast_dtype=torch.bfloat16 if use_amp else None, warmup=1)
+                    loss, y_pred = gstep.warm_loss, gstep.warm_out   # the warm-up step WAS this batch's training step
+                else:
+                    loss = gstep(img, label.long())
+                    y_pred = gstep.out
+                correct += (label == torch.argmax(y_pred, dim=1)).sum()
+                total += label.size(0)
+                running += loss.detach()
+                steps += 1
+                if steps_per_epoch and steps >= steps_per_epoch:
+                    break
+                continue
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=use_amp and not distill):  # distill: use_amp False, train.py:299
                 if distill:
                     student_logits, _ = model(img, return_features=True)
@@ -165,6 +194,8 @@ def train(config_path, mixer="permut", epochs=1, steps_per_epoch=None, batch_siz
             if val_acc > best_acc or epoch == 0:  # train.py:288-290
                 best_acc = max(best_acc, val_acc)
                 torch.save(model.state_dict(), os.path.join(out_dir, "model_best.pt"))
+    if gstep is not None:
+        gstep.close()
     if rank == 0:
         log_f.write(json.dumps({"Training time": time.perf_counter() - start}) + "\n")
         log_f.close()
@@ -179,9 +210,10 @@ def main():
     ap.add_argument("--steps-per-epoch", type=int, default=None)
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--distill", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the training step from HIP graphs (spectre_vit.graph)")
     ap.add_argument("--out", default="runs/spectre_vit")
     a = ap.parse_args()
-    train(a.config, a.mixer, a.epochs, a.steps_per_epoch, a.batch_size, distill=a.distill, out_dir=a.out)
+    train(a.config, a.mixer, a.epochs, a.steps_per_epoch, a.batch_size, distill=a.distill, out_dir=a.out, graph=a.graph)
 
 
 if __name__ == "__main__":
