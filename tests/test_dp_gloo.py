@@ -26,7 +26,7 @@ def _model():
     return torch.nn.Sequential(torch.nn.Linear(12, 32), torch.nn.GELU(), torch.nn.LayerNorm(32), torch.nn.Linear(32, 5))
 
 
-def _worker(rank, world, port, bucket_mb, outdir):
+def _worker(rank, world, port, bucket_mb, outdir, overlap=True):
     sys.path.insert(0, PKG)
     from spectre_vit.dp import GradReducer, broadcast_module
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -37,25 +37,31 @@ def _worker(rank, world, port, bucket_mb, outdir):
             for p in m.parameters():
                 p.add_(1.0)
     broadcast_module(m)
-    red = GradReducer(m, bucket_mb=bucket_mb)
+    red = GradReducer(m, bucket_mb=bucket_mb, overlap=overlap)
+    if not overlap:
+        # the exchange of spectre_vit.graph.GraphedDPStep: ONE flat buffer behind all buckets, nothing launched by the hooks
+        assert red.flat is not None and all(b["flat"].untyped_storage().data_ptr() == red.flat.untyped_storage().data_ptr() for b in red.buckets)
     g = torch.Generator().manual_seed(99)
     x, y = torch.randn(8, 12, generator=g), torch.randint(0, 5, (8,), generator=g)
     xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
     for _ in range(2):  # two steps: buckets are re-armed by zero_grad
         red.zero_grad()
         torch.nn.functional.cross_entropy(m(xs), ys).backward()
-        red.finish()
+        if not overlap:
+            assert all(b["handle"] is None for b in red.buckets)   # no collective was started during the backward pass
+        red.finish()   # overlap=False: allreduce_flat() -- one call over the flat buffer
     torch.save((rank, [p.grad.clone() for p in m.parameters()], [p.detach().clone() for p in m.parameters()]),
                os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("overlap", [True, False])  # bucket all-reduces during the backward pass / one all-reduce of the flat buffer after it
 @pytest.mark.parametrize("bucket_mb", [32.0, 0.0005])  # one bucket / several tiny buckets
-def test_grad_reducer_two_ranks(bucket_mb, tmp_path):
+def test_grad_reducer_two_ranks(bucket_mb, overlap, tmp_path):
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_mb, str(tmp_path))) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_mb, str(tmp_path), overlap)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
