@@ -1099,6 +1099,106 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_kernel(TnBatch tb, float* _
                                t - tb.first_tile[j], split);
 }
 
+#ifdef SPV_LAB   // measured 5 % slower than the one-buffer kernel: lab build only
+// The same 128 x 128 tile on TWO LDS buffers and ONE barrier per K-tile.  tn_tile_body above stores a K-tile, waits at a barrier,
+// multiplies, waits at a second barrier: inside a workgroup nothing overlaps, and its ablations put the sum of
+// exposed loads, LDS stores and MFMAs at the kernel's time.  Here the registers of K-tile t + 1 go to the OTHER buffer between the
+// k-steps of tile t (the store issue hides under that tile's MFMAs), the set is refilled with tile t + 4, and one barrier both
+// publishes tile t + 1 and frees tile t's buffer.  81 920 B of LDS: two workgroups per CU, as many as the 192 registers allow anyway.
+template <typename TO>
+__device__ __forceinline__ void tn_tile_body_db(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
+                                                float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc, int k_per_split,
+                                                int accumulate, int tiles_n, int tile, int split, int tiles_m = 0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tdb_smem[];   // 2 x 40 960 B
+    constexpr int BUF = 2 * TBK * TROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool m_fast = tiles_m > 0 && tiles_n >= 4 * tiles_m;
+    const int tm = m_fast ? tile % tiles_m : tile / tiles_n, tn = m_fast ? tile / tiles_m : tile % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int srow = tid >> 4, sch = tid & 15;
+    const bool a_ok = (m0 + sch * 8) < M, b_ok = (n0 + sch * 8) < N;
+    typedef uint4 RegTile[TBK / 16];
+    RegTile ra0, rb0, ra1, rb1, ra2, rb2;
+    auto load_tile = [&](int k0, RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TBK / 16; ++i) {
+            const int k = k0 + srow + 16 * i;
+            const bool kin = k < kend;
+            ra[i] = (kin && a_ok) ? *reinterpret_cast<const uint4*>(A + (size_t)k * lda + m0 + sch * 8) : make_uint4(0, 0, 0, 0);
+            rb[i] = (kin && b_ok) ? *reinterpret_cast<const uint4*>(B + (size_t)k * ldb + n0 + sch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_half = [&](unsigned char* buf, const RegTile& ra, const RegTile& rb, int half) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 2 * half; i < 2 * half + 2; ++i) {
+            *reinterpret_cast<uint4*>(buf + (srow + 16 * i) * TROWB + sch * 16) = ra[i];
+            *reinterpret_cast<uint4*>(buf + TBK * TROWB + (srow + 16 * i) * TROWB + sch * 16) = rb[i];
+        }
+    };
+    static_assert(TBK / 16 == 4, "two halves of two row groups");
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const int frag_off = (8 * (g >> 1) + q) * TROWB + (16 * (g & 1) + 4 * pp) * 2;
+    const int fa_off = frag_off + (wm * 64) * 2, fb_off = TBK * TROWB + frag_off + (wn * 64) * 2;
+    // one K-tile: multiply from `cur`; between its k-steps the registers of the NEXT tile go to `nxt`; then that set is refilled
+    auto step = [&](int k0, const unsigned char* cur, unsigned char* nxt, RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
+        const bool more = k0 + TBK < kend;       // (ra, rb) hold tile k0 + TBK
+#pragma unroll
+        for (int ks = 0; ks < TBK / 16; ++ks) {
+            bf16x8 a[2], b[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                a[f] = tr_frag(cur + fa_off + ks * 16 * TROWB + f * 64);
+                b[f] = tr_frag(cur + fb_off + ks * 16 * TROWB + f * 64);
+            }
+            if (ks < 2 && more) store_half(nxt, ra, rb, ks);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (k0 + 4 * TBK < kend) load_tile(k0 + 4 * TBK, ra, rb);
+        __syncthreads();
+    };
+    load_tile(kbeg, ra0, rb0);
+    if (kbeg + TBK < kend) load_tile(kbeg + TBK, ra1, rb1);
+    if (kbeg + 2 * TBK < kend) load_tile(kbeg + 2 * TBK, ra2, rb2);
+    store_half(tdb_smem, ra0, rb0, 0);
+    store_half(tdb_smem, ra0, rb0, 1);
+    if (kbeg + 3 * TBK < kend) load_tile(kbeg + 3 * TBK, ra0, rb0);
+    __syncthreads();
+    // tile t is multiplied from buffer t & 1; the register sets rotate with period 3: (ra1, ra2, ra0) hold tiles t + 1 for t = 0, 1, 2
+    int t = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += 3 * TBK, t += 3) {
+        step(k0, tdb_smem + (t & 1) * BUF, tdb_smem + ((t + 1) & 1) * BUF, ra1, rb1);
+        if (k0 + TBK < kend) step(k0 + TBK, tdb_smem + ((t + 1) & 1) * BUF, tdb_smem + (t & 1) * BUF, ra2, rb2);
+        if (k0 + 2 * TBK < kend) step(k0 + 2 * TBK, tdb_smem + (t & 1) * BUF, tdb_smem + ((t + 1) & 1) * BUF, ra0, rb0);
+    }
+    store_acc_tile<TO>(acc, tdb_smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_batch_db_kernel(TnBatch tb, float* __restrict__ ws, int K, int k_per_split, int nsplit) {
+    const int total = tb.first_tile[tb.nprob];
+    const int lin = xcd_remap(blockIdx.x, total * nsplit);
+    const int split = lin / total, t = lin % total;
+    int j = 0;
+    while (j + 1 < tb.nprob && t >= tb.first_tile[j + 1]) ++j;   // workgroup-uniform
+    const TnBatch::P& q = tb.p[j];
+    tn_tile_body_db<float>(q.A, q.B, q.C, ws + tb.ws_off[j], q.M, q.N, K, q.lda, q.ldb, q.ldc, k_per_split, 0, q.tiles_n, t - tb.first_tile[j], split);
+}
+
+#endif  // SPV_LAB
+
 // ---------------------------------------------------------------------------------------------------------
 // TN contraction, WIDE tile: 256 (m) x 128 (n) per 8-wave workgroup (waves 4 x 2, 64 x 64 each), otherwise gemm_tn_kernel's
 // structure (register-staged tiles three K-tiles deep, one LDS buffer, transposing fragment reads).  The weight gradients of the
@@ -1905,10 +2005,16 @@ static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int
             hipLaunchKernelGGL(gemm_tn_batch_wide_kernel, dim3(wt * splits), dim3(512), WSMEM, st, tw, static_cast<float*>(workspace), K, k_per_split, splits);
             SPV_COUNT_PATH(SPV_PATH_GEMM_TN_WIDE);
         } else {
+#ifdef SPV_LAB
             static const int bdepth = SPV_LAB_INT("SPV_TNB_DEPTH", 3);
-            if (bdepth == 5 && k_per_split >= 10 * TBK)
+            if (SPV_LAB_INT("SPV_TNB_DB", 0) && k_per_split >= 8 * TBK) {
+                constexpr int DBSMEM = 2 * 2 * TBK * TROWB;
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_batch_db_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DBSMEM);
+                hipLaunchKernelGGL(gemm_tn_batch_db_kernel, dim3(tiles * splits), dim3(256), DBSMEM, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+            } else if (bdepth == 5 && k_per_split >= 10 * TBK)
                 hipLaunchKernelGGL(gemm_tn_batch_kernel<5>, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
             else
+#endif
                 hipLaunchKernelGGL(gemm_tn_batch_kernel<3>, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
         }
         SPV_LAUNCH_CHECK("spv_gemm_tn_batch");
