@@ -378,6 +378,11 @@ def main():
         sys.exit(self_launch(args, argv))  # before torch / HIP are touched in this process
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL on this driver), also under an external launcher
+    # stdout carries ONE JSON line and nothing else: native libraries write there too (RCCL prints a five-line version banner to
+    # stdout when a communicator is created), so file descriptor 1 points at stderr until the line itself is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -593,7 +598,10 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(args.mixer, args.batch, args.cpu_steps)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(rec), flush=True)
+        os.dup2(2, 1)   # (whatever is printed while the process winds down goes to stderr again)
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 

@@ -24,6 +24,7 @@ def test_bench_self_launches_two_ranks():
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-2000:]   # nothing but the line on stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 32
     assert rec["config"]["parallelism"] == "dp2" and rec["backend"] == "gloo" and "rehearsal" in rec["config"]

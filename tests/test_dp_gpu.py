@@ -243,7 +243,10 @@ def test_bench_single_gpu_line_has_variants_and_cpu_baseline():
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--batch", "64", "--cpu-steps", "1"]
     r = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    # stdout is the ONE JSON line and nothing else (RCCL prints a version banner to stdout when the dp_sequence leg creates its
+    # one-rank communicator: bench.py points file descriptor 1 at stderr until the line is printed)
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[:2000]
+    rec = json.loads(r.stdout)
     assert rec["n_gpus"] == 1 and set(rec["variants"]) == {"permut", "dwt_embed"}
     assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["value"] > 0
     assert rec["roofline"]["bound"] in ("hbm", "mfma") and 0 < rec["roofline"]["frac"] < 1
