@@ -356,6 +356,24 @@ def script_leg(args, mixer, dev, steps, warmup):
                 final_loss=round(float(last), 4))
 
 
+def dp_sequence_child(args, steps, warmup):
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp-sequence", "--steps", str(steps), "--warmup", str(warmup), "--mixer", args.mixer,
+           "--batch", str(args.batch), "--dtype", args.dtype, "--no-cpu-baseline", "--no-roofline", "--no-every-row", "--no-script-leg",
+           "--no-base224", "--variants", "none"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"child exited with {r.returncode}: {r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else 'no output'}"}
+        c = json.loads(line[-1])
+        return dict(value=c["value"], unit="images/sec", ms_per_step=c["ms_per_step"], steps=steps, launch="dp_graph", final_loss=c["final_loss"],
+                    collective=("torch.distributed all_reduce in a one-rank RCCL group" if c.get("rccl_ranks") == 1 else "skipped (no process group)"),
+                    gradient_exchange=c.get("gradient_exchange"), process="child process (python bench.py --dp-sequence)")
+    except Exception as exc:  # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def one_rank_group(dev):
     """a one-rank RCCL process group in this process (single-GPU --dp-sequence leg: the collective call of a rank is issued for real)"""
     import torch.distributed as dist
@@ -587,10 +605,10 @@ def main():
         if variants != "none":
             rec["variants"] = {mx: side_leg(args, mx, dev, sync, "graph", vsteps, vwarm) for mx in variants.split(",") if mx}
         if not args.no_dp_sequence:
-            # what ONE rank of the N-GPU job executes, measured on this GPU: two graphs around the (one-rank) collective call
-            fc = one_rank_group(dev)
-            rec["dp_sequence"] = side_leg(args, args.mixer, dev, sync, "dp_graph", vsteps, vwarm, force_collective=fc)
-            rec["dp_sequence"]["collective"] = "torch.distributed all_reduce in a one-rank RCCL group" if fc else "skipped (no process group)"
+            # what ONE rank of the N-GPU job executes, measured on this GPU: two graphs around the (one-rank) collective call.  Run as
+            # a CHILD process (`bench.py --dp-sequence`): creating an RCCL communicator is the one thing in this file that has never
+            # been exercised by the driver, and a native crash there must not take the headline line with it.
+            rec["dp_sequence"] = dp_sequence_child(args, vsteps, vwarm)
         if not args.no_script_leg:
             rec["as_script"] = script_leg(args, args.mixer, dev, vsteps, vwarm)
         if not args.no_base224 and args.mixer == "fft" and args.batch == 512:

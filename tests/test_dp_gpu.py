@@ -252,7 +252,8 @@ def test_bench_single_gpu_line_has_variants_and_cpu_baseline():
     assert rec["roofline"]["bound"] in ("hbm", "mfma") and 0 < rec["roofline"]["frac"] < 1
     assert rec["config"]["launch"].startswith("one HIP graph") and rec["ms_per_step"] > 0 and rec["eager"]["ms_per_step"] > 0  # headline = graph replay
     assert all(v["launch"] == "graph" for v in rec["variants"].values())   # the variants are timed in the headline's launch mode
-    assert rec["dp_sequence"]["launch"] == "dp_graph" and rec["dp_sequence"]["ms_per_step"] > 0   # a rank's two-graph sequence, one GPU
+    assert rec["dp_sequence"]["launch"] == "dp_graph" and rec["dp_sequence"]["ms_per_step"] > 0, rec["dp_sequence"]   # a rank's two-graph sequence, one GPU
+    assert rec["dp_sequence"]["gradient_exchange"]["calls_per_step"] == 1
     assert rec["as_script"]["ms_per_step"] > 0 and rec["every_row_of_last_layer"]["ms_per_step"] > 0
     assert not [k for k in rec["kernels"] if k.get("frac", 0) > 1.0], [k for k in rec["kernels"] if k.get("frac", 0) > 1.0]
     assert rec["roofline"]["kernel"] in {k["kernel"] for k in rec["kernels"]}
