@@ -593,29 +593,40 @@ def main():
                                                   "gradient are those of the every-row computation (tests/test_gpu_bench_shapes.py runs both forms against the oracle); "
                                                   "the every-row step is timed beside it under \"every_row_of_last_layer\" (SPV_FULL_LAST_LAYER=1 selects it)"
                                                   if hip_ops.LAST_LAYER_CLS_ONLY else "every row")
+        def guarded(fn, *a, **kw):
+            """a side leg must never cost the headline its line: an exception becomes the leg's record"""
+            try:
+                return fn(*a, **kw)
+            except Exception as exc:  # noqa: BLE001
+                torch.cuda.empty_cache()
+                return {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
+
         if hip_ops.LAST_LAYER_CLS_ONLY and not args.no_every_row:
             hip_ops.LAST_LAYER_CLS_ONLY = False
             try:
-                rec["every_row_of_last_layer"] = side_leg(args, args.mixer, dev, sync, "graph", vsteps, vwarm)
+                rec["every_row_of_last_layer"] = guarded(side_leg, args, args.mixer, dev, sync, "graph", vsteps, vwarm)
             finally:
                 hip_ops.LAST_LAYER_CLS_ONLY = True
         variants = args.variants
         if variants is None:
             variants = "permut,dwt_embed" if args.mixer == "fft" else "none"
         if variants != "none":
-            rec["variants"] = {mx: side_leg(args, mx, dev, sync, "graph", vsteps, vwarm) for mx in variants.split(",") if mx}
+            rec["variants"] = {mx: guarded(side_leg, args, mx, dev, sync, "graph", vsteps, vwarm) for mx in variants.split(",") if mx}
         if not args.no_dp_sequence:
             # what ONE rank of the N-GPU job executes, measured on this GPU: two graphs around the (one-rank) collective call.  Run as
             # a CHILD process (`bench.py --dp-sequence`): creating an RCCL communicator is the one thing in this file that has never
             # been exercised by the driver, and a native crash there must not take the headline line with it.
             rec["dp_sequence"] = dp_sequence_child(args, vsteps, vwarm)
         if not args.no_script_leg:
-            rec["as_script"] = script_leg(args, args.mixer, dev, vsteps, vwarm)
+            rec["as_script"] = guarded(script_leg, args, args.mixer, dev, vsteps, vwarm)
         if not args.no_base224 and args.mixer == "fft" and args.batch == 512:
-            rec["base224_student"] = base224_leg(dev)
+            rec["base224_student"] = guarded(base224_leg, dev)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"] = cpu_baseline(args.mixer, args.batch, args.cpu_steps)
+            try:
+                rec["cpu_baseline"] = cpu_baseline(args.mixer, args.batch, args.cpu_steps)
+            except Exception as exc:  # noqa: BLE001
+                rec["cpu_baseline"] = {"error": f"{type(exc).__name__}: {str(exc)[:300]}"}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(rec), flush=True)
