@@ -924,6 +924,7 @@ __global__ __launch_bounds__(256) void gemm_nt_rows_kernel(const bf16_t* __restr
 // transposing LDS read: per 16-lane group it reads a 4 (k) x 16 (m) block and hands lane i column i.  With the
 // 320-byte row stride the four k rows of a group land in four disjoint 16-bank ranges (conflict free).
 typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef unsigned tn_u32x4 __attribute__((ext_vector_type(4)));
 #ifdef SPV_LAB
 __device__ int g_tn_ablate = 0;   // set by the host from SPV_TN_ABLATE before a launch (lab build only)
 #endif
@@ -963,25 +964,53 @@ __device__ __forceinline__ void tn_tile_body(const bf16_t* __restrict__ A, const
     // staging map: TBK k rows x 16 chunks of 16 B per operand -> TBK / 16 chunks per thread per operand
     const int srow = tid >> 4, sch = tid & 15;  // rows srow + 16 i
     const bool a_ok = (m0 + sch * 8) < M, b_ok = (n0 + sch * 8) < N;  // M, N multiples of 8: a chunk is all in or all out
+    const bool edge = m0 + BM > M || n0 + BN > N;                     // uniform: some lane's chunk lies outside the matrix
     // Three register sets: the loads of K-tiles t+1 .. t+3 are in flight while tile t is multiplied.  With the weight
     // gradient's 288 workgroups (~1 per CU, one wave per SIMD) a K-tile is 16 MFMAs = 0.27 us of work per wave, far less
     // than an HBM round trip: with one tile in flight the kernel ran at one K-tile per load latency (43 tiles x ~0.95 us).
-    typedef uint4 RegTile[TBK / 16];
+    // The loads of the pipelined loop are UNCONDITIONAL (see tn_wide_body: predicated loads cost the counted waits): a lane whose
+    // chunk lies outside the matrix reads column 0 instead and zeroes the value before the LDS store; a prefetch past the slice's
+    // last full tile is clamped to that tile; a partial last tile takes the predicated loads behind the loop.
+    typedef tn_u32x4 RegTile[TBK / 16];
     RegTile ra0, rb0, ra1, rb1, ra2, rb2;
-    auto load_tile = [&](int k0, RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
+    uint32_t aoff[TBK / 16], boff[TBK / 16];
+#pragma unroll
+    for (int i = 0; i < TBK / 16; ++i) {
+        aoff[i] = (uint32_t)(((size_t)(srow + 16 * i) * lda + (a_ok ? m0 + sch * 8 : 0)) * 2);
+        boff[i] = (uint32_t)(((size_t)(srow + 16 * i) * ldb + (b_ok ? n0 + sch * 8 : 0)) * 2);
+    }
+    const int nfull = (kend - kbeg) / TBK, krem = (kend - kbeg) % TBK;
+    auto load_full = [&](int t, RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
+        const int k0 = kbeg + min(t, nfull - 1) * TBK;   // uniform
+        const unsigned char* ab = reinterpret_cast<const unsigned char*>(A + (size_t)k0 * lda);
+        const unsigned char* bb = reinterpret_cast<const unsigned char*>(B + (size_t)k0 * ldb);
+#pragma unroll
+        for (int i = 0; i < TBK / 16; ++i) {
+            ra[i] = *reinterpret_cast<const tn_u32x4*>(ab + aoff[i]);
+            rb[i] = *reinterpret_cast<const tn_u32x4*>(bb + boff[i]);
+        }
+    };
+    auto load_partial = [&](int k0, RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TBK / 16; ++i) {
             const int k = k0 + srow + 16 * i;
             const bool kin = k < kend;
-            ra[i] = (kin && a_ok) ? *reinterpret_cast<const uint4*>(A + (size_t)k * lda + m0 + sch * 8) : make_uint4(0, 0, 0, 0);
-            rb[i] = (kin && b_ok) ? *reinterpret_cast<const uint4*>(B + (size_t)k * ldb + n0 + sch * 8) : make_uint4(0, 0, 0, 0);
+            ra[i] = (kin && a_ok) ? *reinterpret_cast<const tn_u32x4*>(A + (size_t)k * lda + m0 + sch * 8) : tn_u32x4{0u, 0u, 0u, 0u};
+            rb[i] = (kin && b_ok) ? *reinterpret_cast<const tn_u32x4*>(B + (size_t)k * ldb + n0 + sch * 8) : tn_u32x4{0u, 0u, 0u, 0u};
         }
     };
-    auto store_tile = [&](const RegTile& ra, const RegTile& rb) __attribute__((always_inline)) {
+    auto store_tile = [&](RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
+        if (edge) {
+#pragma unroll
+            for (int i = 0; i < TBK / 16; ++i) {
+                if (!a_ok) ra[i] = tn_u32x4{0u, 0u, 0u, 0u};
+                if (!b_ok) rb[i] = tn_u32x4{0u, 0u, 0u, 0u};
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TBK / 16; ++i) {
-            *reinterpret_cast<uint4*>(sA + (srow + 16 * i) * TROWB + sch * 16) = ra[i];
-            *reinterpret_cast<uint4*>(sB + (srow + 16 * i) * TROWB + sch * 16) = rb[i];
+            *reinterpret_cast<tn_u32x4*>(sA + (srow + 16 * i) * TROWB + sch * 16) = ra[i];
+            *reinterpret_cast<tn_u32x4*>(sB + (srow + 16 * i) * TROWB + sch * 16) = rb[i];
         }
     };
 
@@ -1015,46 +1044,51 @@ __device__ __forceinline__ void tn_tile_body(const bf16_t* __restrict__ A, const
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
-    // one K-tile: its registers go to LDS, the set is refilled with the tile three ahead, then the MFMAs
 #ifdef SPV_LAB
     const int abl = g_tn_ablate;   // lab: 1 = no LDS stores, 2 = no global loads after the prologue, 4 = no MFMAs / fragment reads (wrong results)
 #else
     constexpr int abl = 0;
 #endif
-    auto step = [&](int k0, RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
+    // one K-tile: its registers go to LDS, the set is refilled with full tile `next` (DEPTH ahead), then the MFMAs
+    auto step = [&](int next, RegTile& ra, RegTile& rb) __attribute__((always_inline)) {
         if (!(abl & 1)) store_tile(ra, rb);
         __syncthreads();
-        if (!(abl & 2) && k0 + DEPTH * TBK < kend) load_tile(k0 + DEPTH * TBK, ra, rb);
+        if (!(abl & 2)) load_full(next, ra, rb);
+        if (!(abl & 4)) multiply();
+        __syncthreads();
+    };
+    auto step_last = [&](RegTile& ra, RegTile& rb) __attribute__((always_inline)) {   // no refill
+        if (!(abl & 1)) store_tile(ra, rb);
+        __syncthreads();
         if (!(abl & 4)) multiply();
         __syncthreads();
     };
 
-    load_tile(kbeg, ra0, rb0);
     if constexpr (DEPTH == 3) {
-        if (kbeg + TBK < kend) load_tile(kbeg + TBK, ra1, rb1);
-        if (kbeg + 2 * TBK < kend) load_tile(kbeg + 2 * TBK, ra2, rb2);
-        for (int k0 = kbeg; k0 < kend; k0 += 3 * TBK) {
-            step(k0, ra0, rb0);
-            if (k0 + TBK < kend) step(k0 + TBK, ra1, rb1);
-            if (k0 + 2 * TBK < kend) step(k0 + 2 * TBK, ra2, rb2);
+        if (nfull > 0) {
+            load_full(0, ra0, rb0);
+            load_full(1, ra1, rb1);
+            load_full(2, ra2, rb2);
+            int t = 0;
+            for (; t + 3 <= nfull; t += 3) {
+                step(t + 3, ra0, rb0);
+                step(t + 4, ra1, rb1);
+                step(t + 5, ra2, rb2);
+            }
+            if (t < nfull) {
+                step_last(ra0, rb0);
+                if (t + 1 < nfull) step_last(ra1, rb1);
+            }
         }
-    } else if constexpr (DEPTH == 5) {
-        // five K-tiles of operand rows in flight (160 staging VGPRs: one wave per SIMD and workgroup, two workgroups per CU): the
-        // batched launch, whose ablations put the exposed operand loads at a third of its time with three in flight
-        RegTile ra3, rb3, ra4, rb4;
-        if (kbeg + TBK < kend) load_tile(kbeg + TBK, ra1, rb1);
-        if (kbeg + 2 * TBK < kend) load_tile(kbeg + 2 * TBK, ra2, rb2);
-        if (kbeg + 3 * TBK < kend) load_tile(kbeg + 3 * TBK, ra3, rb3);
-        if (kbeg + 4 * TBK < kend) load_tile(kbeg + 4 * TBK, ra4, rb4);
-        for (int k0 = kbeg; k0 < kend; k0 += 5 * TBK) {
-            step(k0, ra0, rb0);
-            if (k0 + TBK < kend) step(k0 + TBK, ra1, rb1);
-            if (k0 + 2 * TBK < kend) step(k0 + 2 * TBK, ra2, rb2);
-            if (k0 + 3 * TBK < kend) step(k0 + 3 * TBK, ra3, rb3);
-            if (k0 + 4 * TBK < kend) step(k0 + 4 * TBK, ra4, rb4);
+    } else {   // one K-tile in flight
+        for (int t = 0; t < nfull; ++t) {
+            load_full(t, ra0, rb0);
+            step_last(ra0, rb0);
         }
-    } else {
-        for (int k0 = kbeg; k0 < kend; k0 += TBK) step(k0, ra0, rb0);
+    }
+    if (krem > 0) {
+        load_partial(kbeg + nfull * TBK, ra0, rb0);
+        step_last(ra0, rb0);
     }
     store_acc_tile<TO>(acc, smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr);
 }
@@ -1208,11 +1242,11 @@ __global__ __launch_bounds__(256) void gemm_tn_batch_db_kernel(TnBatch tb, float
 constexpr int TWM = 256;              // tile rows (m)
 constexpr int TWROWA = TWM * 2 + 64;  // LDS bytes per k row of the A tile: 576 = 64 mod 256, the four k rows of a read group land in disjoint banks
 
-template <typename TO>
+template <typename TO, bool DB>
 __device__ __forceinline__ void tn_wide_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
                                              float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc,
                                              int k_per_split, int accumulate, int tiles_n, int tile, int split) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];  // max(A + B tiles = 57 344 B, epilogue 8 x 9 216 B)
+    extern __shared__ __attribute__((aligned(16))) unsigned char tw_smem[];  // TW_SMEM / TW_SMEM_DB bytes
     unsigned char* sA = tw_smem;
     unsigned char* sB = tw_smem + TBK * TWROWA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1221,28 +1255,53 @@ __device__ __forceinline__ void tn_wide_body(const bf16_t* __restrict__ A, const
     const int kbeg = split * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
 
-    // staging map: A = 64 k rows x 32 chunks of 16 B -> 4 per thread (rows arow + 16 i); B = 64 x 16 chunks -> 2 per thread
+    // staging map: A = 64 k rows x 32 chunks of 16 B -> 4 per thread (rows arow + 16 i); B = 64 x 16 chunks -> 2 per thread.
+    // Addresses = a uniform K-tile base (SGPRs) + a per-lane 32-bit offset inside the tile.  The loads of the pipelined loop are
+    // UNCONDITIONAL straight-line code: with every load in its own `k < kend ? load : 0` branch (rounds 1-3) the compiler could not
+    // count the loads in flight and put `s_waitcnt vmcnt(0)` in front of every LDS store -- the "three K-tiles in flight" were one
+    // multiply phase of prefetch, and the kernel ran at load latency + LDS stores + MFMAs added up (ISA + ablations).
+    // A prefetch past the slice's last full tile is clamped to that tile (in bounds, never consumed); a partial last tile (K-slices
+    // that are not multiples of 64 rows) takes the predicated loads, once, behind the loop.
     const int arow = tid >> 5, ach = tid & 31, brow = tid >> 4, bch = tid & 15;
-    const bool a_ok = (m0 + ach * 8) < M, b_ok = (n0 + bch * 8) < N;
-    struct RegTile { uint4 a[4], b[2]; };
-    RegTile r0, r1, r2;
-    auto load_tile = [&](int k0, RegTile& r) __attribute__((always_inline)) {
+    typedef tn_u32x4 RegA[4];   // native vectors: a tile of HIP uint4 structs that is only copied in and out stays an alloca (scratch)
+    typedef tn_u32x4 RegB[2];
+    RegA a0, a1, a2;
+    RegB b0, b1, b2;
+    uint32_t aoff[4], boff[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoff[i] = (uint32_t)(((size_t)(arow + 16 * i) * lda + ach * 8) * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) boff[i] = (uint32_t)(((size_t)(brow + 32 * i) * ldb + bch * 8) * 2);
+    const int nfull = (kend - kbeg) / TBK, krem = (kend - kbeg) % TBK;
+    auto load_full = [&](int t, RegA& ra, RegB& rb) __attribute__((always_inline)) {
+        const int k0 = kbeg + min(t, nfull - 1) * TBK;   // uniform
+        const unsigned char* ab = reinterpret_cast<const unsigned char*>(A + (size_t)k0 * lda + m0);
+        const unsigned char* bb = reinterpret_cast<const unsigned char*>(B + (size_t)k0 * ldb + n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const tn_u32x4*>(ab + aoff[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const tn_u32x4*>(bb + boff[i]);
+    };
+    auto load_partial = [&](int k0, RegA& ra, RegB& rb) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + arow + 16 * i;
-            r.a[i] = (k < kend && a_ok) ? *reinterpret_cast<const uint4*>(A + (size_t)k * lda + m0 + ach * 8) : make_uint4(0, 0, 0, 0);
+            ra[i] = k < kend ? *reinterpret_cast<const tn_u32x4*>(A + (size_t)k * lda + m0 + ach * 8) : tn_u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = k0 + brow + 32 * i;
-            r.b[i] = (k < kend && b_ok) ? *reinterpret_cast<const uint4*>(B + (size_t)k * ldb + n0 + bch * 8) : make_uint4(0, 0, 0, 0);
+            rb[i] = k < kend ? *reinterpret_cast<const tn_u32x4*>(B + (size_t)k * ldb + n0 + bch * 8) : tn_u32x4{0u, 0u, 0u, 0u};
         }
     };
-    auto store_tile = [&](const RegTile& r) __attribute__((always_inline)) {
+    // the six 16-byte LDS stores of a register tile; part ks of 4 (2 + 2 + 1 + 1 stores) or all of them (ks < 0)
+    auto store_part = [&](int boff_lds, const RegA& ra, const RegB& rb, int ks) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(sA + (arow + 16 * i) * TWROWA + ach * 16) = r.a[i];
+        for (int i = 0; i < 4; ++i)
+            if (ks < 0 || ks == (i >> 1)) *reinterpret_cast<tn_u32x4*>(sA + boff_lds + (arow + 16 * i) * TWROWA + ach * 16) = ra[i];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(sB + (brow + 32 * i) * TROWB + bch * 16) = r.b[i];
+        for (int i = 0; i < 2; ++i)
+            if (ks < 0 || ks == 2 + i) *reinterpret_cast<tn_u32x4*>(sB + boff_lds + (brow + 32 * i) * TROWB + bch * 16) = rb[i];
     };
 
     f32x16 acc[2][2];
@@ -1264,53 +1323,135 @@ __device__ __forceinline__ void tn_wide_body(const bf16_t* __restrict__ A, const
         const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     };
-    auto multiply = [&]() __attribute__((always_inline)) {
+#ifdef SPV_LAB
+    const int abl = g_tn_ablate;   // lab: 1 = no LDS stores, 2 = no global loads after the prologue, 4 = no MFMAs / fragment reads (wrong results)
+#else
+    constexpr int abl = 0;
+#endif
+    // the 16 MFMAs of the K-tile in buffer `cur`; between its k-steps (STORE) the register tile (ra, rb) goes to buffer `nxt`
+    auto multiply = [&](int cur, auto store_tag, int nxt, const RegA& ra, const RegB& rb) __attribute__((always_inline)) {
+        constexpr bool STORE = decltype(store_tag)::value;
 #pragma unroll
         for (int ks = 0; ks < TBK / 16; ++ks) {
             bf16x8 a[2], b[2];
+            if (!(abl & 4)) {
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                a[f] = fragA(fa0 + ks * 16 * TWROWA + f * 64);
-                b[f] = tr_frag(fb0 + ks * 16 * TROWB + f * 64);
+                for (int f = 0; f < 2; ++f) {
+                    a[f] = fragA(fa0 + cur + ks * 16 * TWROWA + f * 64);
+                    b[f] = tr_frag(fb0 + cur + ks * 16 * TROWB + f * 64);
+                }
             }
+            if constexpr (STORE) {
+                if (!(abl & 1)) store_part(nxt, ra, rb, ks);
+            }
+            if (!(abl & 4)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
-    auto step = [&](int k0, RegTile& r) __attribute__((always_inline)) {
-        store_tile(r);
-        __syncthreads();
-        if (k0 + 3 * TBK < kend) load_tile(k0 + 3 * TBK, r);
-        multiply();
-        __syncthreads();
-    };
+    using yes = std::true_type;
+    using no = std::false_type;
 
-    load_tile(kbeg, r0);
-    if (kbeg + TBK < kend) load_tile(kbeg + TBK, r1);
-    if (kbeg + 2 * TBK < kend) load_tile(kbeg + 2 * TBK, r2);
-    for (int k0 = kbeg; k0 < kend; k0 += 3 * TBK) {
-        step(k0, r0);
-        if (k0 + TBK < kend) step(k0 + TBK, r1);
-        if (k0 + 2 * TBK < kend) step(k0 + 2 * TBK, r2);
+    if constexpr (DB) {
+        // TWO LDS buffers, ONE barrier per K-tile: while tile t is multiplied out of buffer t & 1, the registers of tile t + 1 go to
+        // the other buffer between the k-steps (the 13-cycle ds_write_b128 issues hide under the MFMAs), that register set is
+        // refilled with tile t + 4, and the barrier both publishes tile t + 1 and frees tile t's buffer.  Register sets rotate with
+        // period 3 (tile j lives in set j % 3), buffers with period 2.
+        constexpr int WBUF = TBK * TWROWA + TBK * TROWB;
+        if (nfull > 0) {
+            load_full(0, a0, b0);
+            load_full(1, a1, b1);
+            load_full(2, a2, b2);
+            store_part(0, a0, b0, -1);
+            load_full(3, a0, b0);
+            __syncthreads();
+            auto step = [&](int t, RegA& ra, RegB& rb) __attribute__((always_inline)) {   // (ra, rb) hold tile t + 1
+                multiply((t & 1) * WBUF, yes{}, ((t + 1) & 1) * WBUF, ra, rb);
+                if (!(abl & 2)) load_full(t + 4, ra, rb);
+                __syncthreads();
+            };
+            auto step_noload = [&](int t, const RegA& ra, const RegB& rb) __attribute__((always_inline)) {
+                multiply((t & 1) * WBUF, yes{}, ((t + 1) & 1) * WBUF, ra, rb);
+                __syncthreads();
+            };
+            int t = 0;
+            for (; t + 4 <= nfull; t += 3) {
+                step(t, a1, b1);
+                step(t + 1, a2, b2);
+                step(t + 2, a0, b0);
+            }
+            const int left = nfull - t;   // 1, 2 or 3 tiles: t in buffer t & 1, t + 1 in (a1, b1), t + 2 in (a2, b2)
+            if (left >= 2) {
+                step_noload(t, a1, b1);
+                if (left == 3) step_noload(t + 1, a2, b2);
+            }
+            multiply(((nfull - 1) & 1) * WBUF, no{}, 0, a0, b0);
+            __syncthreads();
+        }
+        if (krem > 0) {
+            load_partial(kbeg + nfull * TBK, a0, b0);
+            store_part(0, a0, b0, -1);
+            __syncthreads();
+            multiply(0, no{}, 0, a0, b0);
+            __syncthreads();
+        }
+    } else {
+        // one buffer, two barriers per K-tile: store, barrier, refill, multiply, barrier
+        auto step = [&](int next, RegA& ra, RegB& rb) __attribute__((always_inline)) {
+            if (!(abl & 1)) store_part(0, ra, rb, -1);
+            __syncthreads();
+            if (!(abl & 2)) load_full(next, ra, rb);
+            multiply(0, no{}, 0, ra, rb);
+            __syncthreads();
+        };
+        auto step_last = [&](const RegA& ra, const RegB& rb) __attribute__((always_inline)) {   // no refill
+            if (!(abl & 1)) store_part(0, ra, rb, -1);
+            __syncthreads();
+            multiply(0, no{}, 0, ra, rb);
+            __syncthreads();
+        };
+        if (nfull > 0) {
+            load_full(0, a0, b0);
+            load_full(1, a1, b1);
+            load_full(2, a2, b2);
+            int t = 0;
+            for (; t + 3 <= nfull; t += 3) {
+                step(t + 3, a0, b0);
+                step(t + 4, a1, b1);
+                step(t + 5, a2, b2);
+            }
+            if (t < nfull) {
+                step_last(a0, b0);
+                if (t + 1 < nfull) step_last(a1, b1);
+            }
+        }
+        if (krem > 0) {
+            load_partial(kbeg + nfull * TBK, a0, b0);
+            step_last(a0, b0);
+        }
     }
     store_acc_tile<TO>(acc, tw_smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr, nullptr, 0, 0, wm * 64, wn * 64);
 }
 
-template <typename TO>
+constexpr int TW_SMEM = 8 * 9216;                                   // one K-tile buffer (57 344 B) < the epilogue's 8 x 9 216 B
+constexpr int TW_SMEM_DB = 2 * (TBK * TWROWA + TBK * TROWB);       // two K-tile buffers: 114 688 B
+template <typename TO, bool DB>
 __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
                                                            float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc,
                                                            int k_per_split, int accumulate, int tiles_n, int tiles_mn, int nsplit) {
     const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);  // whole K-slices per XCD (see gemm_tn_kernel)
-    tn_wide_body<TO>(A, B, C, ws, M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, lin % tiles_mn, lin / tiles_mn);
+    tn_wide_body<TO, DB>(A, B, C, ws, M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, lin % tiles_mn, lin / tiles_mn);
 }
 
 // the batched launch on the 256 x 128 tile: every problem's M a multiple of 256, N of 128 (the encoder layers' 768 x 512 / 512 x 768
 // weight gradients: 12 tiles each).  The batched 128 x 128 kernel moves 2.45 GB through the L2 -> LDS path for the six 33 280-row
 // gradients of a step (144 us at the ~17 TB/s that path sustains chip-wide, against 75 us of MFMA issue); this tile moves 1.84 GB.
 // tb.first_tile / tiles_n count WIDE tiles here.
+template <bool DB>
 __global__ __launch_bounds__(512) void gemm_tn_batch_wide_kernel(TnBatch tb, float* __restrict__ ws, int K, int k_per_split, int nsplit) {
     const int total = tb.first_tile[tb.nprob];
     const int lin = xcd_remap(blockIdx.x, total * nsplit);
@@ -1318,8 +1459,8 @@ __global__ __launch_bounds__(512) void gemm_tn_batch_wide_kernel(TnBatch tb, flo
     int j = 0;
     while (j + 1 < tb.nprob && t >= tb.first_tile[j + 1]) ++j;   // workgroup-uniform
     const TnBatch::P& q = tb.p[j];
-    tn_wide_body<float>(q.A, q.B, q.C, ws + tb.ws_off[j], q.M, q.N, K, q.lda, q.ldb, q.ldc, k_per_split, 0, q.tiles_n,
-                        t - tb.first_tile[j], split);
+    tn_wide_body<float, DB>(q.A, q.B, q.C, ws + tb.ws_off[j], q.M, q.N, K, q.lda, q.ldb, q.ldc, k_per_split, 0, q.tiles_n,
+                            t - tb.first_tile[j], split);
 }
 
 #ifdef SPV_LAB   // measured slower inside the training step: kept for the lab build only
@@ -1868,16 +2009,19 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
         // kernel).  Measured in graph mode, alternating: 2.372 vs 2.385 ms/step -- 1.6 us per launch; without split-K (the MHPermutMix
         // weight gradient, 512 x 8192 x 33 280) it is SLOWER (651 vs 510 us), hence splits >= 4
         const int wt = (M / TWM) * tiles_n;
-        constexpr int WSMEM = 8 * 9216;
+        static const int wide_db = SPV_LAB_INT("SPV_TN_WIDE_DB", 1);   // two LDS buffers, one barrier per K-tile
+#define SPV_TNW(TOV, DBV, SM)                                                                                                             \
+    do {                                                                                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<TOV, DBV>), hipFuncAttributeMaxDynamicSharedMemorySize, SM); \
+        hipLaunchKernelGGL((gemm_tn_wide_kernel<TOV, DBV>), dim3(wt * splits), dim3(512), SM, st, (const bf16_t*)A, (const bf16_t*)B, (TOV*)C,   \
+                           ws, M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, wt, splits);                                     \
+    } while (0)
         if (out_dtype == SPV_BF16) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, WSMEM);
-            hipLaunchKernelGGL((gemm_tn_wide_kernel<bf16_t>), dim3(wt * splits), dim3(512), WSMEM, st, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C,
-                               ws, M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, wt, splits);
+            if (wide_db) SPV_TNW(bf16_t, true, TW_SMEM_DB); else SPV_TNW(bf16_t, false, TW_SMEM);
         } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_wide_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, WSMEM);
-            hipLaunchKernelGGL((gemm_tn_wide_kernel<float>), dim3(wt * splits), dim3(512), WSMEM, st, (const bf16_t*)A, (const bf16_t*)B, (float*)C, ws,
-                               M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, wt, splits);
+            if (wide_db) SPV_TNW(float, true, TW_SMEM_DB); else SPV_TNW(float, false, TW_SMEM);
         }
+#undef SPV_TNW
         SPV_LAUNCH_CHECK("spv_gemm_tn(wide)");
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN_WIDE);
     } else {
@@ -1981,8 +2125,12 @@ static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int
     hipStream_t st = static_cast<hipStream_t>(stream);
 #ifdef SPV_LAB
     {
+        static int last_abl = 0;
         const int abl = SPV_LAB_INT("SPV_TN_ABLATE", 0);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tn_ablate), &abl, sizeof(abl));
+        if (abl != last_abl) {   // (a copy per launch cost every timed launch ~60 us of host synchronisation)
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tn_ablate), &abl, sizeof(abl));
+            last_abl = abl;
+        }
     }
 #endif
     // the 256 x 128 tile when every problem divides into it and the K-slices are long enough to pay for its longer prologue
@@ -2000,9 +2148,14 @@ static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int
                 wt += (probs[i].m / TWM) * cdiv(probs[i].n, BN);
             }
             tw.first_tile[nprob] = wt;
-            constexpr int WSMEM = 8 * 9216;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_batch_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WSMEM);
-            hipLaunchKernelGGL(gemm_tn_batch_wide_kernel, dim3(wt * splits), dim3(512), WSMEM, st, tw, static_cast<float*>(workspace), K, k_per_split, splits);
+            static const int wide_db = SPV_LAB_INT("SPV_TN_WIDE_DB", 1);   // two LDS buffers, one barrier per K-tile
+            if (wide_db) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_batch_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_SMEM_DB);
+                hipLaunchKernelGGL(gemm_tn_batch_wide_kernel<true>, dim3(wt * splits), dim3(512), TW_SMEM_DB, st, tw, static_cast<float*>(workspace), K, k_per_split, splits);
+            } else {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_batch_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_SMEM);
+                hipLaunchKernelGGL(gemm_tn_batch_wide_kernel<false>, dim3(wt * splits), dim3(512), TW_SMEM, st, tw, static_cast<float*>(workspace), K, k_per_split, splits);
+            }
             SPV_COUNT_PATH(SPV_PATH_GEMM_TN_WIDE);
         } else {
 #ifdef SPV_LAB
@@ -2011,8 +2164,8 @@ static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int
                 constexpr int DBSMEM = 2 * 2 * TBK * TROWB;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_batch_db_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DBSMEM);
                 hipLaunchKernelGGL(gemm_tn_batch_db_kernel, dim3(tiles * splits), dim3(256), DBSMEM, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
-            } else if (bdepth == 5 && k_per_split >= 10 * TBK)
-                hipLaunchKernelGGL(gemm_tn_batch_kernel<5>, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+            } else if (bdepth == 1)
+                hipLaunchKernelGGL(gemm_tn_batch_kernel<1>, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
             else
 #endif
                 hipLaunchKernelGGL(gemm_tn_batch_kernel<3>, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
