@@ -134,6 +134,8 @@ typedef struct spv_tn_problem {
     const void* b;
     void* c;
     int m, n, lda, ldb, ldc;
+    int k;   /* rows THIS problem reduces over: 0 or K = the call's K (split-K as asked); 1..K-1 = a short problem (the CLS-only last
+              * layer's 512-row gradients beside the 33 280-row ones): its first k rows, unsplit, stored by the GEMM launch itself */
 } spv_tn_problem;
 int spv_gemm_tn_batch(const spv_tn_problem* probs, int nprob, int K, int splits, void* workspace, const spv_fold_job* folds, int nfolds,
                       void* stream);

@@ -497,9 +497,9 @@ def test_held_weight_gradients_run_as_one_batch():
         single = grads(False)
         assert not calls
         batched = grads(True)
-        # 3 layers x (linear1, linear3): one launch -- or, with the last layer's feed-forward half at the CLS rows only (the default),
-        # that layer's two (K = 96 rows) apart from the other four (K = 96 x 65)
-        assert sorted(calls) == ([2, 4] if hip_ops.LAST_LAYER_CLS_ONLY else [6]), calls
+        # 3 layers x (linear1, linear3): ONE launch -- with the last layer's feed-forward half at the CLS rows only (the default) that
+        # layer's two gradients (K = 96 rows) ride in it as short problems beside the other four (K = 96 x 65)
+        assert sorted(calls) == [6], calls
     finally:
         _native.call = orig_call
         hip_ops._native.call = orig_call

@@ -114,7 +114,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // out[p][c] = sum_w partials[w][p][c] (p < np <= 5, c < n), in a fixed order.  One 1024-thread workgroup covers FOLD_COLS columns;
 // block `bid` of cdiv(np * n, FOLD_COLS).  Used by the row kernels' own fold launch and -- so that the backward of a layer does not
 // pay a launch for it -- as extra workgroups of the weight gradient's split-K reduce (spv_gemm_tn_fold).
-constexpr int FOLD_COLS = 16, FOLD_ROWS = 64;
+// A wave reads 2 partial rows x 32 columns = two whole 128-byte lines per load instruction (16 columns x 64 thread rows, rounds 1-3, read
+// 64-byte half lines: the fold workgroups riding in the batched weight gradients' reduce were 27 of its 40 us).
+constexpr int FOLD_COLS = 32, FOLD_ROWS = 32;
 struct FoldJob {
     const float* partials;
     float* o[5];
@@ -128,20 +130,20 @@ __device__ __forceinline__ void fold_partials_block(const FoldJob& j, int bid, i
     const float* partials = j.partials;
     float s = 0.0f;
     if (c < total) {
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = 0.0f;
         int w = py;
-        for (; w + 3 * FOLD_ROWS < j.parts; w += 4 * FOLD_ROWS) {
-            s0 += partials[(size_t)w * total + c];
-            s1 += partials[(size_t)(w + FOLD_ROWS) * total + c];
-            s2 += partials[(size_t)(w + 2 * FOLD_ROWS) * total + c];
-            s3 += partials[(size_t)(w + 3 * FOLD_ROWS) * total + c];
+        for (; w + 7 * FOLD_ROWS < j.parts; w += 8 * FOLD_ROWS) {   // eight independent loads in flight per thread
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += partials[(size_t)(w + u * FOLD_ROWS) * total + c];
         }
-        for (; w < j.parts; w += FOLD_ROWS) s0 += partials[(size_t)w * total + c];
-        s = (s0 + s1) + (s2 + s3);
+        for (; w < j.parts; w += FOLD_ROWS) a[0] += partials[(size_t)w * total + c];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
     red[py][cx] = s;
     __syncthreads();
-    // 64 -> 4 -> 1 in a fixed order
+    // FOLD_ROWS -> 4 -> 1 in a fixed order
     if (py < 4) {
         float t = 0.0f;
 #pragma unroll

@@ -1112,25 +1112,51 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
 constexpr int TNB_MAX = 8;
 struct TnBatch {
     int nprob;
+    int nlong;                    // problems [0, nlong) reduce over the call's K rows in nsplit slices; the rest over their own (fewer) rows, unsplit
     int first_tile[TNB_MAX + 1];
-    long long ws_off[TNB_MAX];   // floats into the workspace: nsplit slabs of M x N per problem, problem after problem
+    long long ws_off[TNB_MAX];   // floats into the workspace: nsplit slabs of M x N per LONG problem, problem after problem
     struct P {
         const bf16_t* A;
         const bf16_t* B;
         float* C;
-        int M, N, lda, ldb, ldc, tiles_n;
+        int M, N, lda, ldb, ldc, tiles_n, K;
     } p[TNB_MAX];
 };
-template <int DEPTH>
-__global__ __launch_bounds__(256) void gemm_tn_batch_kernel(TnBatch tb, float* __restrict__ ws, int K, int k_per_split, int nsplit) {
-    const int total = tb.first_tile[tb.nprob];
-    const int lin = xcd_remap(blockIdx.x, total * nsplit);
-    const int split = lin / total, t = lin % total;
+// which (problem, tile, K-slice) this workgroup computes: the long problems' tiles slice after slice (XCD-remapped as a whole, see
+// gemm_tn_kernel), then the short problems' tiles (the CLS-only last layer's 512-row gradients: one short workgroup each instead of a
+// launch + a reduce of their own behind the big one)
+struct TnWork {
+    int j, tile, split, K, k_per_split;
+    float* ws;
+};
+__device__ __forceinline__ TnWork tn_batch_work(const TnBatch& tb, float* ws, int K, int k_per_split, int nsplit) {
+    // The short tiles take the FIRST workgroup ids (padded to a multiple of 8 so that the long part keeps its XCD mapping; the pad
+    // workgroups leave at once): a short workgroup is a tenth of a long one, and dispatched first it only delays the CUs it lands on
+    // by that much -- appended behind 504 long workgroups (two full rounds at one per CU) the 24 short ones pushed 16 long workgroups
+    // into a third round (+35 us per launch).
+    const int long_tiles = tb.first_tile[tb.nlong];
+    const int short_tiles = tb.first_tile[tb.nprob] - long_tiles;
+    const int short_pad = (short_tiles + 7) & ~7;
+    int split = 0, t;
+    if ((int)blockIdx.x < short_pad) {
+        if ((int)blockIdx.x >= short_tiles) return {-1, 0, 0, 0, 0, nullptr};
+        t = long_tiles + (int)blockIdx.x;
+    } else {
+        const int lin = xcd_remap(blockIdx.x - short_pad, long_tiles * nsplit);
+        split = lin / long_tiles;
+        t = lin % long_tiles;
+    }
     int j = 0;
     while (j + 1 < tb.nprob && t >= tb.first_tile[j + 1]) ++j;   // workgroup-uniform
-    const TnBatch::P& q = tb.p[j];
-    tn_tile_body<float, DEPTH>(q.A, q.B, q.C, ws + tb.ws_off[j], q.M, q.N, K, q.lda, q.ldb, q.ldc, k_per_split, 0, q.tiles_n,
-                               t - tb.first_tile[j], split);
+    const bool is_long = j < tb.nlong;
+    return {j, t - tb.first_tile[j], split, is_long ? K : tb.p[j].K, is_long ? k_per_split : tb.p[j].K, is_long ? ws + tb.ws_off[j] : nullptr};
+}
+template <int DEPTH>
+__global__ __launch_bounds__(256) void gemm_tn_batch_kernel(TnBatch tb, float* __restrict__ ws, int K, int k_per_split, int nsplit) {
+    const TnWork w = tn_batch_work(tb, ws, K, k_per_split, nsplit);
+    if (w.j < 0) return;
+    const TnBatch::P& q = tb.p[w.j];
+    tn_tile_body<float, DEPTH>(q.A, q.B, q.C, w.ws, q.M, q.N, w.K, q.lda, q.ldb, q.ldc, w.k_per_split, 0, q.tiles_n, w.tile, w.split);
 }
 
 #ifdef SPV_LAB   // measured 5 % slower than the one-buffer kernel: lab build only
@@ -1222,13 +1248,10 @@ __device__ __forceinline__ void tn_tile_body_db(const bf16_t* __restrict__ A, co
 }
 
 __global__ __launch_bounds__(256) void gemm_tn_batch_db_kernel(TnBatch tb, float* __restrict__ ws, int K, int k_per_split, int nsplit) {
-    const int total = tb.first_tile[tb.nprob];
-    const int lin = xcd_remap(blockIdx.x, total * nsplit);
-    const int split = lin / total, t = lin % total;
-    int j = 0;
-    while (j + 1 < tb.nprob && t >= tb.first_tile[j + 1]) ++j;   // workgroup-uniform
-    const TnBatch::P& q = tb.p[j];
-    tn_tile_body_db<float>(q.A, q.B, q.C, ws + tb.ws_off[j], q.M, q.N, K, q.lda, q.ldb, q.ldc, k_per_split, 0, q.tiles_n, t - tb.first_tile[j], split);
+    const TnWork w = tn_batch_work(tb, ws, K, k_per_split, nsplit);
+    if (w.j < 0) return;
+    const TnBatch::P& q = tb.p[w.j];
+    tn_tile_body_db<float>(q.A, q.B, q.C, w.ws, q.M, q.N, w.K, q.lda, q.ldb, q.ldc, w.k_per_split, 0, q.tiles_n, w.tile, w.split);
 }
 
 #endif  // SPV_LAB
@@ -1453,14 +1476,10 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
 // tb.first_tile / tiles_n count WIDE tiles here.
 template <bool DB>
 __global__ __launch_bounds__(512) void gemm_tn_batch_wide_kernel(TnBatch tb, float* __restrict__ ws, int K, int k_per_split, int nsplit) {
-    const int total = tb.first_tile[tb.nprob];
-    const int lin = xcd_remap(blockIdx.x, total * nsplit);
-    const int split = lin / total, t = lin % total;
-    int j = 0;
-    while (j + 1 < tb.nprob && t >= tb.first_tile[j + 1]) ++j;   // workgroup-uniform
-    const TnBatch::P& q = tb.p[j];
-    tn_wide_body<float, DB>(q.A, q.B, q.C, ws + tb.ws_off[j], q.M, q.N, K, q.lda, q.ldb, q.ldc, k_per_split, 0, q.tiles_n,
-                            t - tb.first_tile[j], split);
+    const TnWork w = tn_batch_work(tb, ws, K, k_per_split, nsplit);
+    if (w.j < 0) return;
+    const TnBatch::P& q = tb.p[w.j];
+    tn_wide_body<float, DB>(q.A, q.B, q.C, w.ws, q.M, q.N, w.K, q.lda, q.ldb, q.ldc, w.k_per_split, 0, q.tiles_n, w.tile, w.split);
 }
 
 #ifdef SPV_LAB   // measured slower inside the training step: kept for the lab build only
@@ -1747,7 +1766,7 @@ __global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void splitk_reduce_batch_ker
         fold_jobs_block(fj, (int)blockIdx.x, threadIdx.x);
     } else {   // all 1024 threads sum (eight problems are 786 k four-column quads: 768 workgroups)
         const int b = (int)blockIdx.x - fold_blocks;
-        const int j = b / reduce_blocks;
+        const int j = b / reduce_blocks;   // (the launch has reduce_blocks workgroups per LONG problem: short ones stored their result)
         const TnBatch::P& q = tb.p[j];
         splitk_reduce_body<float>(ws + tb.ws_off[j], nullptr, q.C, q.M, q.N, q.ldc, splits, 0, b % reduce_blocks, reduce_blocks, threadIdx.x,
                                   FOLD_COLS * FOLD_ROWS);
@@ -2106,20 +2125,38 @@ static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int
     int k_per_split = cdiv(cdiv(K, splits), TBK) * TBK;
     splits = cdiv(K, k_per_split);
     int reduce_blocks = 1;
+    // the long problems (k == 0 or k == K: the call's K rows, split-K) first, then the short ones (k < K: their own rows, unsplit, stored
+    // by the GEMM launch itself); order[] maps the kernel's problem index to the caller's
+    int order[TNB_MAX], nlong = 0, no = 0;
     for (int i = 0; i < nprob; ++i) {
-        const spv_tn_problem& q = probs[i];
-        SPV_CHECK(q.a != nullptr && q.b != nullptr && q.c != nullptr && q.m > 0 && q.n > 0, "spv_gemm_tn_batch: empty problem %d", i);
+        SPV_CHECK(probs[i].k >= 0 && probs[i].k <= K, "spv_gemm_tn_batch: problem %d: k=%d must be 0 (= K) or 1..K=%d", i, probs[i].k, K);
+        if (probs[i].k == 0 || probs[i].k == K) order[no++] = i;
+    }
+    nlong = no;
+    for (int i = 0; i < nprob; ++i)
+        if (!(probs[i].k == 0 || probs[i].k == K)) order[no++] = i;
+    SPV_CHECK(nlong >= 1, "spv_gemm_tn_batch: no problem reduces over the call's K=%d rows", K);
+    tb.nlong = nlong;
+    int long_tiles = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const spv_tn_problem& q = probs[order[i]];
+        SPV_CHECK(q.a != nullptr && q.b != nullptr && q.c != nullptr && q.m > 0 && q.n > 0, "spv_gemm_tn_batch: empty problem %d", order[i]);
         SPV_CHECK(q.m % 8 == 0 && q.n % 8 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.lda >= q.m && q.ldb >= q.n && q.ldc >= q.n,
-                  "spv_gemm_tn_batch: problem %d: M=%d N=%d lda=%d ldb=%d ldc=%d (multiples of 8, leading dimensions >= extents)", i, q.m, q.n,
-                  q.lda, q.ldb, q.ldc);
-        SPV_CHECK(((uintptr_t)q.a & 15) == 0 && ((uintptr_t)q.b & 15) == 0, "spv_gemm_tn_batch: problem %d: A/B must be 16-byte aligned", i);
+                  "spv_gemm_tn_batch: problem %d: M=%d N=%d lda=%d ldb=%d ldc=%d (multiples of 8, leading dimensions >= extents)", order[i], q.m,
+                  q.n, q.lda, q.ldb, q.ldc);
+        SPV_CHECK(((uintptr_t)q.a & 15) == 0 && ((uintptr_t)q.b & 15) == 0, "spv_gemm_tn_batch: problem %d: A/B must be 16-byte aligned", order[i]);
+        SPV_CHECK(i < nlong || q.ldc % 4 == 0, "spv_gemm_tn_batch: problem %d (short): ldc=%d must be a multiple of 4", order[i], q.ldc);
         tb.first_tile[i] = tiles;
         tb.ws_off[i] = off;
-        tb.p[i] = {static_cast<const bf16_t*>(q.a), static_cast<const bf16_t*>(q.b), static_cast<float*>(q.c), q.m, q.n, q.lda, q.ldb, q.ldc, cdiv(q.n, BN)};
+        tb.p[i] = {static_cast<const bf16_t*>(q.a), static_cast<const bf16_t*>(q.b), static_cast<float*>(q.c), q.m, q.n, q.lda, q.ldb, q.ldc, cdiv(q.n, BN),
+                   i < nlong ? K : q.k};
         tiles += cdiv(q.m, BM) * cdiv(q.n, BN);
-        off += (long long)splits * q.m * q.n;
-        constexpr int RT = FOLD_COLS * FOLD_ROWS;
-        reduce_blocks = std::max(reduce_blocks, (int)std::min<int64_t>(((int64_t)q.m * q.n / ((q.n & 3) == 0 ? 4 : 1) + RT - 1) / RT, 2048));
+        if (i < nlong) {
+            long_tiles = tiles;
+            off += (long long)splits * q.m * q.n;
+            constexpr int RT = FOLD_COLS * FOLD_ROWS;
+            reduce_blocks = std::max(reduce_blocks, (int)std::min<int64_t>(((int64_t)q.m * q.n / ((q.n & 3) == 0 ? 4 : 1) + RT - 1) / RT, 2048));
+        }
     }
     tb.first_tile[nprob] = tiles;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2136,39 +2173,42 @@ static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int
     // the 256 x 128 tile when every problem divides into it and the K-slices are long enough to pay for its longer prologue
     static const int wide_env = SPV_LAB_INT("SPV_TNB_WIDE", 1);
     bool wide = wide_env != 0 && k_per_split >= 8 * TBK;
-    for (int i = 0; i < nprob && wide; ++i) wide = probs[i].m % TWM == 0 && probs[i].n % BN == 0;
+    for (int i = 0; i < nprob && wide; ++i) wide = probs[i].m % TWM == 0 && probs[i].n % BN == 0 && (probs[i].k == 0 || probs[i].k >= TBK);
     if (parts & 1) {
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN);
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN_BATCH);
         if (wide) {
             TnBatch tw = tb;
-            int wt = 0;
+            int wt = 0, wlong = 0;
             for (int i = 0; i < nprob; ++i) {
                 tw.first_tile[i] = wt;
-                wt += (probs[i].m / TWM) * cdiv(probs[i].n, BN);
+                wt += (tb.p[i].M / TWM) * tb.p[i].tiles_n;
+                if (i < nlong) wlong = wt;
             }
             tw.first_tile[nprob] = wt;
+            const int wgrid = wlong * splits + ((wt - wlong + 7) & ~7);
             static const int wide_db = SPV_LAB_INT("SPV_TN_WIDE_DB", 1);   // two LDS buffers, one barrier per K-tile
             if (wide_db) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_batch_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_SMEM_DB);
-                hipLaunchKernelGGL(gemm_tn_batch_wide_kernel<true>, dim3(wt * splits), dim3(512), TW_SMEM_DB, st, tw, static_cast<float*>(workspace), K, k_per_split, splits);
+                hipLaunchKernelGGL(gemm_tn_batch_wide_kernel<true>, dim3(wgrid), dim3(512), TW_SMEM_DB, st, tw, static_cast<float*>(workspace), K, k_per_split, splits);
             } else {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_batch_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TW_SMEM);
-                hipLaunchKernelGGL(gemm_tn_batch_wide_kernel<false>, dim3(wt * splits), dim3(512), TW_SMEM, st, tw, static_cast<float*>(workspace), K, k_per_split, splits);
+                hipLaunchKernelGGL(gemm_tn_batch_wide_kernel<false>, dim3(wgrid), dim3(512), TW_SMEM, st, tw, static_cast<float*>(workspace), K, k_per_split, splits);
             }
             SPV_COUNT_PATH(SPV_PATH_GEMM_TN_WIDE);
         } else {
+            const int grid128 = long_tiles * splits + ((tiles - long_tiles + 7) & ~7);
 #ifdef SPV_LAB
             static const int bdepth = SPV_LAB_INT("SPV_TNB_DEPTH", 3);
             if (SPV_LAB_INT("SPV_TNB_DB", 0) && k_per_split >= 8 * TBK) {
                 constexpr int DBSMEM = 2 * 2 * TBK * TROWB;
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_batch_db_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DBSMEM);
-                hipLaunchKernelGGL(gemm_tn_batch_db_kernel, dim3(tiles * splits), dim3(256), DBSMEM, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+                hipLaunchKernelGGL(gemm_tn_batch_db_kernel, dim3(grid128), dim3(256), DBSMEM, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
             } else if (bdepth == 1)
-                hipLaunchKernelGGL(gemm_tn_batch_kernel<1>, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+                hipLaunchKernelGGL(gemm_tn_batch_kernel<1>, dim3(grid128), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
             else
 #endif
-                hipLaunchKernelGGL(gemm_tn_batch_kernel<3>, dim3(tiles * splits), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
+                hipLaunchKernelGGL(gemm_tn_batch_kernel<3>, dim3(grid128), dim3(256), 0, st, tb, static_cast<float*>(workspace), K, k_per_split, splits);
         }
         SPV_LAUNCH_CHECK("spv_gemm_tn_batch");
     }
@@ -2176,7 +2216,7 @@ static int gemm_tn_batch_impl(const spv_tn_problem* probs, int nprob, int K, int
         FoldJobs fj{};
         int fold_blocks = 0;
         SPV_CHECK(fill_fold_jobs(folds, nfolds, fj, fold_blocks) == 0, "spv_gemm_tn_batch: bad fold job");
-        hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(fold_blocks + nprob * reduce_blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, tb,
+        hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3(fold_blocks + nlong * reduce_blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, tb,
                            static_cast<const float*>(workspace), splits, reduce_blocks, fj);
         SPV_LAUNCH_CHECK("spv_gemm_tn_batch(split-k reduce + fold)");
     }

@@ -355,34 +355,57 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(const T* __restrict
     *reinterpret_cast<float4*>(po + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
-// dpos[t][e] = sum_groups partials; dbias[e] = sum_{t >= 1} dpos[t][e]; dcls[e] = dpos[0][e].  grid = E / 16, 1024 threads = 16 columns x 64 token rows
-__global__ __launch_bounds__(1024) void embed_bwd_fold_kernel(const float* __restrict__ partials, float* __restrict__ dpos, float* __restrict__ dbias,
-                                                             float* __restrict__ dcls, int groups, int T, int E) {
-    __shared__ float red[64][17];
-    const int cx = threadIdx.x & 15, py = threadIdx.x >> 4;
-    const int e = blockIdx.x * 16 + cx;
-    float bsum = 0.0f;
-    if (e < E) {
-        for (int t = py; t < T; t += 64) {
-            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-            for (int w0 = 0; w0 < groups; w0 += 16) {   // sixteen independent loads in flight
-                float q[16];
+// dpos[t][e] = sum_groups partials; dbias[e] = sum_{t >= 1} dpos[t][e]; dcls[e] = dpos[0][e].  1024-thread workgroups of two kinds, both
+// reading only `partials` (no order between workgroups), every sum in a fixed order:
+//   blocks [0, pos_blocks): one column of the flat [T * E] row per thread, its `groups` partials as independent loads;
+//   the rest: 32 columns of dbias each, 32 thread rows sharing the (group, token >= 1) pairs.
+// (One workgroup per 16 columns doing both -- E / 16 = 32 workgroups, 64-byte half lines -- took 73-104 us beside the batched weight
+// gradients and held up the embedding weight gradient behind it on the main stream.)
+constexpr int EF_T = 1024;
+__global__ __launch_bounds__(EF_T) void embed_bwd_fold_kernel(const float* __restrict__ partials, float* __restrict__ dpos, float* __restrict__ dbias,
+                                                             float* __restrict__ dcls, int groups, int T, int E, int pos_blocks) {
+    const int TE = T * E;
+    if ((int)blockIdx.x < pos_blocks) {
+        const int c = blockIdx.x * EF_T + threadIdx.x;
+        if (c >= TE) return;
+        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int g = 0;
+        for (; g + 8 <= groups; g += 8) {
+            float q[8];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) q[j] = partials[((size_t)min(w0 + j, groups - 1) * T + t) * E + e] * (w0 + j < groups ? 1.0f : 0.0f);
+            for (int u = 0; u < 8; ++u) q[u] = partials[(size_t)(g + u) * TE + c];
 #pragma unroll
-                for (int j = 0; j < 16; j += 4) { s0 += q[j]; s1 += q[j + 1]; s2 += q[j + 2]; s3 += q[j + 3]; }
-            }
-            const float v = (s0 + s1) + (s2 + s3);
-            dpos[(size_t)t * E + e] = v;
-            if (t == 0) dcls[e] = v;
-            else bsum += v;
+            for (int u = 0; u < 8; ++u) a[u & 3] += q[u];
         }
+        for (; g < groups; ++g) a[0] += partials[(size_t)g * TE + c];
+        const float v = (a[0] + a[1]) + (a[2] + a[3]);
+        dpos[c] = v;
+        if (c < E) dcls[c] = v;
+        return;
     }
-    red[py][cx] = bsum;
+    __shared__ float red[32][33];
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int e = ((int)blockIdx.x - pos_blocks) * 32 + cx;
+    const int pairs = groups * (T - 1);   // (group, token >= 1)
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.0f;
+    if (e < E) {
+        int p = py;
+        for (; p + 7 * 32 < pairs; p += 8 * 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int pp = p + u * 32;
+                a[u] += partials[((size_t)(pp / (T - 1)) * T + 1 + pp % (T - 1)) * E + e];
+            }
+        }
+        for (; p < pairs; p += 32) a[0] += partials[((size_t)(p / (T - 1)) * T + 1 + p % (T - 1)) * E + e];
+    }
+    red[py][cx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
     if (py == 0 && e < E) {
         float t = 0.0f;
-        for (int q = 0; q < 64; ++q) t += red[q][cx];
+        for (int q = 0; q < 32; ++q) t += red[q][cx];
         dbias[e] = t;
     }
 }
@@ -407,7 +430,9 @@ extern "C" int spv_embed_bwd(const void* g, const void* gcls, void* dtok, float*
         hipLaunchKernelGGL((embed_bwd_rows_kernel<float>), grid, dim3(256), 0, st, (const float*)g, (const float*)gcls, (float*)dtok, partials, batch, TE, embed,
                            p_drop, seed);
     SPV_LAUNCH_CHECK("spv_embed_bwd(rows)");
-    hipLaunchKernelGGL(embed_bwd_fold_kernel, dim3(cdiv(embed, 16)), dim3(1024), 0, st, partials, dpos, dbias, dcls, groups, tokens, embed);
+    const int pos_blocks = cdiv(TE, EF_T);
+    hipLaunchKernelGGL(embed_bwd_fold_kernel, dim3(pos_blocks + cdiv(embed, 32)), dim3(EF_T), 0, st, partials, dpos, dbias, dcls, groups, tokens, embed,
+                       pos_blocks);
     SPV_LAUNCH_CHECK("spv_embed_bwd(fold)");
     return 0;
 }

@@ -115,7 +115,7 @@ class FoldJob(ctypes.Structure):
 
 class TnProblem(ctypes.Structure):
     """spv_tn_problem (include/spv.h): one weight gradient of a spv_gemm_tn_batch launch"""
-    _fields_ = [("a", c_vp), ("b", c_vp), ("c", c_vp), ("m", c_i), ("n", c_i), ("lda", c_i), ("ldb", c_i), ("ldc", c_i)]
+    _fields_ = [("a", c_vp), ("b", c_vp), ("c", c_vp), ("m", c_i), ("n", c_i), ("lda", c_i), ("ldb", c_i), ("ldc", c_i), ("k", c_i)]
 
 
 _lib = None

@@ -515,17 +515,22 @@ def _flush_held_wgrads():
     partials, split-K workspaces): a caller that runs this on a side stream keeps them alive until the streams are joined."""
     used = []
     while _held_wgrads:
-        rows = max(w[3] for w in _held_wgrads)   # the long reductions first: a small batch (the CLS-only last layer's) fills their drain
-        group = [w for w in _held_wgrads if w[3] == rows][:WGRAD_BATCH]
+        # up to eight per launch, the long reductions first; gradients over fewer rows (the CLS-only last layer's: 512) ride in the same
+        # launch as short problems -- one workgroup per tile, no split-K, no launch + reduce of their own behind the big one
+        rows = max(w[3] for w in _held_wgrads)
+        group = sorted(_held_wgrads, key=lambda w: -w[3])[:WGRAD_BATCH]
         taken = {id(w) for w in group}
         _held_wgrads[:] = [w for w in _held_wgrads if id(w) not in taken]   # (by identity: the tuples hold tensors)
         probs = (_native.TnProblem * len(group))()
         tiles = floats = 0
+        flops = 0.0
         folds = []
-        for q, (dh, x, dwp, _, n, k, fold) in zip(probs, group):
-            q.a, q.b, q.c, q.m, q.n, q.lda, q.ldb, q.ldc = _p(dh), _p(x), dwp, n, k, n, k, k
-            tiles += ((n + 127) // 128) * ((k + 127) // 128)
-            floats += n * k
+        for q, (dh, x, dwp, r, n, k, fold) in zip(probs, group):
+            q.a, q.b, q.c, q.m, q.n, q.lda, q.ldb, q.ldc, q.k = _p(dh), _p(x), dwp, n, k, n, k, k, r
+            if r == rows:
+                tiles += ((n + 127) // 128) * ((k + 127) // 128)
+                floats += n * k
+            flops += 2.0 * r * n * k
             used += [dh, x]
             if fold is not None:
                 folds.append(fold)
@@ -537,7 +542,7 @@ def _flush_held_wgrads():
         used += [f[0] for f in folds]   # the folds' partial column sums: read by the reduce launch, long after this function returns
         arr = _fold_array(folds) if folds else None
         if _timing():   # a measuring pass brackets the GEMM launch and the reduce launch separately (same kernels, same order)
-            _native.hint = int(2.0 * rows * floats)
+            _native.hint = int(flops)
             _native.call("spv_gemm_tn_batch_part", ctypes.addressof(probs), len(group), rows, splits, _p(ws), ctypes.addressof(arr) if folds else 0,
                          len(folds), 1, _stream())
             _native.hint = int(4.0 * floats * (splits + 1))
