@@ -2045,7 +2045,11 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN_WIDE);
     } else {
     dim3 grid(tiles_m * tiles_n * splits);
-    static const int depth = SPV_LAB_INT("SPV_TN_DEPTH", 3);  // tuning aid: 1 = one K-tile in flight
+    // One K-tile in flight (144 VGPRs, 40 KB of LDS) for the sliver-shaped gradient of the patch embedding (512 x 48 x 33 280): that
+    // launch runs on the main stream BESIDE the batched layer gradients, whose workgroups (8 waves x 184 VGPRs, 112 KB) leave exactly
+    // 144 VGPRs per SIMD and 45 KB per CU -- with three tiles in flight (216 VGPRs) its workgroups waited for those CUs to drain.
+    static const int depth_env = SPV_LAB_INT("SPV_TN_DEPTH", 0);  // tuning aid: 1 / 3 force a depth
+    const int depth = depth_env ? depth_env : (N <= 64 ? 1 : 3);
 #define SPV_TN(TOV, DV)                                                                                                     \
     hipLaunchKernelGGL((gemm_tn_kernel<TOV, DV>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (TOV*)C, ws, M, N, K, \
                        lda, ldb, ldc, k_per_split, accumulate, tiles_n, tiles_m * tiles_n, splits)

@@ -308,6 +308,55 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(const T* __restrict
 #pragma unroll
     for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
     const bool cls_row = gcls != nullptr && col < E;
+    if constexpr (sizeof(T) == 2) {
+        // bf16: one 16-byte load per row (two 8-byte loads were half the bytes per request)
+        typedef unsigned raw4 __attribute__((ext_vector_type(4)));
+        // (EB_HB rows at a time: < 128 VGPRs, so that this 256-thread workgroup fits on a CU BESIDE a workgroup of the batched weight
+        // gradients -- 8 waves x 184 VGPRs leave 144 per SIMD -- which is where it runs: at 145 it waited for that kernel's CUs to drain)
+        for (int h0 = 0; h0 < EB_GS; h0 += EB_HB) {
+            raw4 xr[EB_HB], cr[EB_HB];
+#pragma unroll
+            for (int s = 0; s < EB_HB; ++s) xr[s] = *reinterpret_cast<const raw4*>(g + (size_t)min(b0 + h0 + s, B - 1) * TE + col);
+            if (cls_row) {   // (one workgroup of the grid's column blocks)
+#pragma unroll
+                for (int s = 0; s < EB_HB; ++s) cr[s] = *reinterpret_cast<const raw4*>(gcls + (size_t)min(b0 + h0 + s, B - 1) * E + col);
+            }
+#pragma unroll
+            for (int s = 0; s < EB_HB; ++s) {
+                const int b = b0 + h0 + s;
+                if (b >= B) break;
+                const size_t i = (size_t)b * TE + col;
+                float x[8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    x[2 * u] = __uint_as_float(xr[s][u] << 16);
+                    x[2 * u + 1] = __uint_as_float(xr[s][u] & 0xffff0000u);
+                }
+                if (cls_row) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        x[2 * u] += __uint_as_float(cr[s][u] << 16);
+                        x[2 * u + 1] += __uint_as_float(cr[s][u] & 0xffff0000u);
+                    }
+                }
+                if (p > 0.0f) {
+                    const unsigned key = dropout_row_key(sd, (uint64_t)i >> 12);
+                    const unsigned c0 = (unsigned)(i & 4095);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] *= dropout_scale(key, c0 + u, p, inv_keep);
+                }
+                raw4 o;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) o[u] = pack_bf16x2(x[2 * u], x[2 * u + 1]);
+                if (dtok != nullptr) *reinterpret_cast<raw4*>(dtok + i) = o;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {   // the sums are taken over what the weight-gradient GEMM reads: the rounded values
+                    acc[2 * u] += __uint_as_float(o[u] << 16);
+                    acc[2 * u + 1] += __uint_as_float(o[u] & 0xffff0000u);
+                }
+            }
+        }
+    } else {
     // EB_HB rows' loads are issued before the first is used (clamped addresses, masked sums): one row per trip was a chain of HBM
     // round trips (25 us for 68 MB)
     for (int h0 = 0; h0 < EB_GS; h0 += EB_HB) {
@@ -338,10 +387,6 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(const T* __restrict
 #pragma unroll
                 for (int u = 0; u < 8; ++u) x[s][u] *= dropout_scale(key, c0 + u, p, inv_keep);
             }
-            if (sizeof(T) == 2) {   // the sums are taken over what the weight-gradient GEMM reads: the rounded values
-#pragma unroll
-                for (int u = 0; u < 8; ++u) x[s][u] = bf2f(f2bf(x[s][u]));
-            }
             if (dtok != nullptr) {
                 io<T>::st4(dtok + i, *reinterpret_cast<const float(*)[4]>(&x[s][0]));
                 io<T>::st4(dtok + i + 4, *reinterpret_cast<const float(*)[4]>(&x[s][4]));
@@ -350,64 +395,50 @@ __global__ __launch_bounds__(256) void embed_bwd_rows_kernel(const T* __restrict
             for (int u = 0; u < 8; ++u) acc[u] += x[s][u];
         }
     }
+    }
     float* po = partials + (size_t)blockIdx.y * TE + col;
     *reinterpret_cast<float4*>(po) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     *reinterpret_cast<float4*>(po + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
 }
 
-// dpos[t][e] = sum_groups partials; dbias[e] = sum_{t >= 1} dpos[t][e]; dcls[e] = dpos[0][e].  1024-thread workgroups of two kinds, both
-// reading only `partials` (no order between workgroups), every sum in a fixed order:
-//   blocks [0, pos_blocks): one column of the flat [T * E] row per thread, its `groups` partials as independent loads;
-//   the rest: 32 columns of dbias each, 32 thread rows sharing the (group, token >= 1) pairs.
-// (One workgroup per 16 columns doing both -- E / 16 = 32 workgroups, 64-byte half lines -- took 73-104 us beside the batched weight
-// gradients and held up the embedding weight gradient behind it on the main stream.)
-constexpr int EF_T = 1024;
-__global__ __launch_bounds__(EF_T) void embed_bwd_fold_kernel(const float* __restrict__ partials, float* __restrict__ dpos, float* __restrict__ dbias,
-                                                             float* __restrict__ dcls, int groups, int T, int E, int pos_blocks) {
-    const int TE = T * E;
-    if ((int)blockIdx.x < pos_blocks) {
-        const int c = blockIdx.x * EF_T + threadIdx.x;
-        if (c >= TE) return;
-        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        int g = 0;
-        for (; g + 8 <= groups; g += 8) {
-            float q[8];
+// dpos[t][e] = sum_groups partials; dcls[e] = dpos[0][e]: one column of the flat [T * E] row per thread, its `groups` partials as
+// independent loads, 256-thread workgroups with few registers -- they run on CUs that the batched weight gradients occupy (one
+// 1024-thread workgroup per 16 columns, E / 16 = 32 of them reading 64-byte half lines, took 73-104 us there and held up the embedding
+// weight gradient behind it on the main stream; so did 1024-thread workgroups of any shape: 16 waves do not fit beside that kernel).
+// dbias[e] = sum_{t >= 1} dpos[t][e] follows as a launch of its own (E / 64 single-wave workgroups over 133 KB that are still in L2).
+constexpr int EF_T = 256;
+__global__ __launch_bounds__(EF_T) void embed_bwd_fold_kernel(const float* __restrict__ partials, float* __restrict__ dpos, float* __restrict__ dcls,
+                                                             int groups, int TE, int E) {
+    const int c = blockIdx.x * EF_T + threadIdx.x;
+    if (c >= TE) return;
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int g = 0;
+    for (; g + 8 <= groups; g += 8) {
+        float q[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) q[u] = partials[(size_t)(g + u) * TE + c];
+        for (int u = 0; u < 8; ++u) q[u] = partials[(size_t)(g + u) * TE + c];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u & 3] += q[u];
-        }
-        for (; g < groups; ++g) a[0] += partials[(size_t)g * TE + c];
-        const float v = (a[0] + a[1]) + (a[2] + a[3]);
-        dpos[c] = v;
-        if (c < E) dcls[c] = v;
-        return;
+        for (int u = 0; u < 8; ++u) a[u & 3] += q[u];
     }
-    __shared__ float red[32][33];
-    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
-    const int e = ((int)blockIdx.x - pos_blocks) * 32 + cx;
-    const int pairs = groups * (T - 1);   // (group, token >= 1)
-    float a[8];
+    for (; g < groups; ++g) a[0] += partials[(size_t)g * TE + c];
+    const float v = (a[0] + a[1]) + (a[2] + a[3]);
+    dpos[c] = v;
+    if (c < E) dcls[c] = v;
+}
+__global__ __launch_bounds__(64) void embed_bwd_bias_kernel(const float* __restrict__ dpos, float* __restrict__ dbias, int T, int E) {
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= E) return;
+    float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int t = 1;
+    for (; t + 8 <= T; t += 8) {
+        float q[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] = 0.0f;
-    if (e < E) {
-        int p = py;
-        for (; p + 7 * 32 < pairs; p += 8 * 32) {
+        for (int u = 0; u < 8; ++u) q[u] = dpos[(size_t)(t + u) * E + e];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int pp = p + u * 32;
-                a[u] += partials[((size_t)(pp / (T - 1)) * T + 1 + pp % (T - 1)) * E + e];
-            }
-        }
-        for (; p < pairs; p += 32) a[0] += partials[((size_t)(p / (T - 1)) * T + 1 + p % (T - 1)) * E + e];
+        for (int u = 0; u < 8; ++u) a[u & 3] += q[u];
     }
-    red[py][cx] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    __syncthreads();
-    if (py == 0 && e < E) {
-        float t = 0.0f;
-        for (int q = 0; q < 32; ++q) t += red[q][cx];
-        dbias[e] = t;
-    }
+    for (; t < T; ++t) a[0] += dpos[(size_t)t * E + e];
+    dbias[e] = (a[0] + a[1]) + (a[2] + a[3]);
 }
 
 extern "C" int spv_embed_bwd_groups(int batch) { return cdiv(batch, EB_GS); }
@@ -430,9 +461,8 @@ extern "C" int spv_embed_bwd(const void* g, const void* gcls, void* dtok, float*
         hipLaunchKernelGGL((embed_bwd_rows_kernel<float>), grid, dim3(256), 0, st, (const float*)g, (const float*)gcls, (float*)dtok, partials, batch, TE, embed,
                            p_drop, seed);
     SPV_LAUNCH_CHECK("spv_embed_bwd(rows)");
-    const int pos_blocks = cdiv(TE, EF_T);
-    hipLaunchKernelGGL(embed_bwd_fold_kernel, dim3(pos_blocks + cdiv(embed, 32)), dim3(EF_T), 0, st, partials, dpos, dbias, dcls, groups, tokens, embed,
-                       pos_blocks);
+    hipLaunchKernelGGL(embed_bwd_fold_kernel, dim3(cdiv(TE, EF_T)), dim3(EF_T), 0, st, partials, dpos, dcls, groups, TE, embed);
+    hipLaunchKernelGGL(embed_bwd_bias_kernel, dim3(cdiv(embed, 64)), dim3(64), 0, st, dpos, dbias, tokens, embed);
     SPV_LAUNCH_CHECK("spv_embed_bwd(fold)");
     return 0;
 }
