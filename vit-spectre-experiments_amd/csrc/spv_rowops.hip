@@ -1406,7 +1406,8 @@ extern "C" int spv_spectre_tail_fwd(const void* h, const void* x, const float* g
     SPV_CHECK((int64_t)n * k_in < (1ll << 31), "spv_spectre_tail_fwd: n*k_in too large");
     {
         const int fast = dtype == SPV_BF16, bfl = dtype == SPV_BF16, obf = out_dtype == SPV_BF16;
-        dim3 lgrid(std::min(cdiv(rows, RW), 2048));
+        static const int fwd_wgs = SPV_LAB_INT("SPV_TAIL_FWD_WGS", 2048);   // tuning aid (lab build)
+        dim3 lgrid(std::min(cdiv(rows, RW), fwd_wgs));
 #define LC_FWD(CO, CI)                                                                                                        \
         if (n == 64 * CO && k_in == 64 * CI && obf == bfl) {                                                                  \
             SPV_COUNT_PATH(SPV_PATH_TAIL_LC); \
@@ -1453,7 +1454,8 @@ static int tail_bwd_impl(const void* dout, const void* h, const float* mean, con
     SPV_CHECK((int64_t)n * k_in < (1ll << 31), "spv_spectre_tail_bwd: n*k_in too large");
     {
         const int fast = dtype == SPV_BF16, bfl = dtype == SPV_BF16, dbf = dout_dtype == SPV_BF16;
-        const int lwgs = std::min(cdiv(rows, RW), BWD_MAX_WG);
+        static const int bwd_wgs = SPV_LAB_INT("SPV_TAIL_BWD_WGS", BWD_MAX_WG);   // tuning aid (lab build), <= BWD_MAX_WG
+        const int lwgs = std::min(cdiv(rows, RW), std::min(bwd_wgs, BWD_MAX_WG));
         // no skip gradient asked for (the data-gradient GEMM adds it in its epilogue): the input width plays no part
         const int k_lc = (dx_pool == nullptr && up.src == nullptr) ? n : k_in;
 #define LC_BWD(CO, CI)                                                                                                        \
