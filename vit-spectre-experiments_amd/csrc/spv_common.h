@@ -122,36 +122,45 @@ struct FoldJob {
     float* o[5];
     int parts, np, n;
 };
+// RPT = thread rows per thread: 1 = FOLD_COLS x FOLD_ROWS threads (1024); 4 = FOLD_COLS x 8 threads (256: a workgroup that fits on a CU
+// BESIDE a workgroup of the batched weight gradients, see spv_fold_multi), each doing four thread rows' sums one after the other --
+// the same additions in the same order, so every fold of the library gives the same bits whichever launch carries it.
+template <int RPT = 1>
 __device__ __forceinline__ void fold_partials_block(const FoldJob& j, int bid, int tid) {
     __shared__ float red[FOLD_ROWS][FOLD_COLS + 1];
-    const int cx = tid % FOLD_COLS, py = tid / FOLD_COLS;
+    constexpr int TROWS = FOLD_ROWS / RPT;   // thread rows of the workgroup
+    const int cx = tid % FOLD_COLS, pq = tid / FOLD_COLS;
     const int c = bid * FOLD_COLS + cx;
     const int total = j.np * j.n;
     const float* partials = j.partials;
-    float s = 0.0f;
-    if (c < total) {
-        float a[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = 0.0f;
-        int w = py;
-        for (; w + 7 * FOLD_ROWS < j.parts; w += 8 * FOLD_ROWS) {   // eight independent loads in flight per thread
+    for (int r = 0; r < RPT; ++r) {
+        const int py = pq + r * TROWS;
+        float s = 0.0f;
+        if (c < total) {
+            float a[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a[u] += partials[(size_t)(w + u * FOLD_ROWS) * total + c];
+            for (int u = 0; u < 8; ++u) a[u] = 0.0f;
+            int w = py;
+            for (; w + 7 * FOLD_ROWS < j.parts; w += 8 * FOLD_ROWS) {   // eight independent loads in flight per thread (and row)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] += partials[(size_t)(w + u * FOLD_ROWS) * total + c];
+            }
+            for (; w < j.parts; w += FOLD_ROWS) a[0] += partials[(size_t)w * total + c];
+            s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         }
-        for (; w < j.parts; w += FOLD_ROWS) a[0] += partials[(size_t)w * total + c];
-        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        red[py][cx] = s;
     }
-    red[py][cx] = s;
     __syncthreads();
     // FOLD_ROWS -> 4 -> 1 in a fixed order
-    if (py < 4) {
+    if (pq < 4) {
         float t = 0.0f;
 #pragma unroll
-        for (int q = 0; q < FOLD_ROWS / 4; ++q) t += red[py * (FOLD_ROWS / 4) + q][cx];
-        red[py * (FOLD_ROWS / 4)][cx] = t;
+        for (int q = 0; q < FOLD_ROWS / 4; ++q) t += red[pq * (FOLD_ROWS / 4) + q][cx];
+        red[pq * (FOLD_ROWS / 4)][cx] = t;
     }
     __syncthreads();
-    if (py == 0 && c < total) {
+    if (pq == 0 && c < total) {
         const float t = (red[0][cx] + red[FOLD_ROWS / 4][cx]) + (red[FOLD_ROWS / 2][cx] + red[3 * FOLD_ROWS / 4][cx]);
         const int p = c / j.n, cc = c % j.n;
         float* o = j.o[p];

@@ -1740,7 +1740,15 @@ __device__ __forceinline__ void fold_jobs_block(const FoldJobs& fj, int bid, int
     while (j + 1 < fj.njobs && bid >= fj.first_block[j + 1]) ++j;   // workgroup-uniform
     fold_partials_block(fj.job[j], bid - fj.first_block[j], tid);
 }
-__global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS) void fold_multi_kernel(FoldJobs fj) { fold_jobs_block(fj, blockIdx.x, threadIdx.x); }
+// the stand-alone fold launch: 256-thread workgroups with few registers, which the dispatcher places on CUs that a workgroup of the batched
+// weight gradients occupies (8 waves x 184 VGPRs and 112 KB leave room for 4 more waves of up to 144) -- hip_ops.start_held_wgrads issues
+// it on the main stream while that kernel runs on the side stream, instead of as extra workgroups of its reduce behind it
+constexpr int FOLD_NARROW = 4;
+__global__ __launch_bounds__(FOLD_COLS * FOLD_ROWS / FOLD_NARROW) void fold_multi_kernel(FoldJobs fj) {
+    int j = 0;
+    while (j + 1 < fj.njobs && (int)blockIdx.x >= fj.first_block[j + 1]) ++j;   // workgroup-uniform
+    fold_partials_block<FOLD_NARROW>(fj.job[j], blockIdx.x - fj.first_block[j], threadIdx.x);
+}
 
 // the split-K reduce of a weight gradient with folds (the same layer's dgamma / dbeta / dbias partials, and any fold held back by an
 // earlier node of the backward) as extra workgroups
@@ -2088,7 +2096,7 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
         SPV_LAUNCH_CHECK("spv_gemm_tn(split-k reduce)");
     }
     if (fold_blocks > 0 && splits <= 1) {   // no reduce to ride on: the fold runs by itself
-        hipLaunchKernelGGL(fold_multi_kernel, dim3(fold_blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, fj);
+        hipLaunchKernelGGL(fold_multi_kernel, dim3(fold_blocks), dim3(FOLD_COLS * FOLD_ROWS / FOLD_NARROW), 0, st, fj);
         SPV_LAUNCH_CHECK("spv_gemm_tn_fold(fold)");
     }
     return 0;
@@ -2111,7 +2119,7 @@ extern "C" int spv_fold_multi(const spv_fold_job* folds, int nfolds, void* strea
         FoldJobs fj{};
         int blocks = 0;
         SPV_CHECK(fill_fold_jobs(folds + j0, std::min(FJ_MAX, nfolds - j0), fj, blocks) == 0, "spv_fold_multi: bad fold job");
-        hipLaunchKernelGGL(fold_multi_kernel, dim3(blocks), dim3(FOLD_COLS * FOLD_ROWS), 0, st, fj);
+        hipLaunchKernelGGL(fold_multi_kernel, dim3(blocks), dim3(FOLD_COLS * FOLD_ROWS / FOLD_NARROW), 0, st, fj);
         SPV_LAUNCH_CHECK("spv_fold_multi");
     }
     return 0;

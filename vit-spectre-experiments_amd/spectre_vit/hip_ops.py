@@ -451,6 +451,9 @@ FOLD_RIDE = not _lab("SPV_NO_FOLD_RIDE", "")    # tail folds ride in their layer
 # step that exchanges its gradients in ONE call after the backward pass (spectre_vit.graph.GraphedDPStep) has no such need and
 # sets this flag while its backward passes run.
 HOLD_UNDER_DP = False
+FOLDS_BESIDE_BATCH = False   # True: start_held_wgrads issues the held folds as their own launch on the main stream, beside the batch,
+# instead of as extra workgroups of its reduce.  Measured (round 3): the reduce drops 29 -> 17 us, but the 68-us fold launch then
+# stands in front of the embedding's backward on the main stream, which becomes the longer chain: window 251 -> 266 us.  Off.
 TIME_HELD = False   # bench.py's roofline pass: bracket the launch sequence the headline times (held + batched weight gradients)
 
 
@@ -509,10 +512,11 @@ def _batch_splits(tiles):
     return best
 
 
-def _flush_held_wgrads():
+def _flush_held_wgrads(folds_out=None):
     """the weight gradients held back during this backward pass: one launch (+ one reduce that carries their folds and the folds held
-    so far) per group of up to eight with the same row count.  Returns every tensor the launches read or write (operands, fold
-    partials, split-K workspaces): a caller that runs this on a side stream keeps them alive until the streams are joined."""
+    so far) per group of up to eight.  Returns every tensor the launches read or write (operands, fold partials, split-K
+    workspaces): a caller that runs this on a side stream keeps them alive until the streams are joined.  folds_out (a list): the
+    folds are NOT given to the reduce but appended to it -- the caller launches them itself (start_held_wgrads: on the main stream)."""
     used = []
     while _held_wgrads:
         # up to eight per launch, the long reductions first; gradients over fewer rows (the CLS-only last layer's: 512) ride in the same
@@ -536,6 +540,9 @@ def _flush_held_wgrads():
                 folds.append(fold)
         while _held_folds and len(folds) < BATCH_FOLDS:
             folds.append(_held_folds.pop(0))
+        if folds_out is not None:
+            folds_out += folds
+            folds = []
         splits = max(1, min(_batch_splits(tiles), rows // 256))   # (the CLS-only last layer: 512 rows)
         ws = torch.empty((splits * floats,), dtype=torch.float32, device=group[0][0].device)
         used.append(ws)
@@ -564,8 +571,18 @@ def start_held_wgrads():
         return False   # (a timed pass keeps the batch on the main stream: its event brackets must not overlap other kernels)
     side = _side_stream(_held_wgrads[0][0].device)
     side.wait_stream(torch.cuda.current_stream())
+    folds = []
     with torch.cuda.stream(side):
-        used = _flush_held_wgrads()
+        used = _flush_held_wgrads(folds if FOLDS_BESIDE_BATCH else None)
+    if folds:
+        # the folds (column sums of the tails' partial slabs: nothing reads them before the optimizer) as ONE launch of 256-thread
+        # workgroups on the MAIN stream: they fit on the CUs beside the batch's workgroups and are done long before it ends -- as
+        # extra workgroups of its reduce they were 16 of that launch's 29 us, behind the batch
+        while _held_folds:
+            folds.append(_held_folds.pop(0))
+        arr = _fold_array(folds)
+        _native.call("spv_fold_multi", ctypes.addressof(arr), len(folds), _stream())
+        used += [f[0] for f in folds]
     # everything the side-stream launches touch stays referenced until join_side_stream(): the operands AND the fold partials (they
     # were allocated on the main stream and had no other owner once the flush returned -- the caching allocator could hand their
     # blocks to the embedding's backward, which runs on the main stream beside the batch, before the reduce has read them)
