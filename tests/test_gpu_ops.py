@@ -170,7 +170,10 @@ def test_gemm_nt_strip_kernel_with_reserved_cus(ops):
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(128, 128, 64, 1), (768, 512, 33280, 12), (104, 48, 1000, 3), (512, 8192, 2600, 2),
-                                          (8, 16, 40, 1), (264, 136, 4100, 5)])
+                                          (8, 16, 40, 1), (264, 136, 4100, 5),
+                                          (768, 512, 8010, 12),    # the 256 x 128 tile with a partial last K-tile in the last slice
+                                          (512, 48, 3000, 16),     # the sliver shape of the patch-embedding gradient (one K-tile in flight)
+                                          (256, 128, 100, 1)])     # fewer rows than one pipelined group of K-tiles
 def test_gemm_tn(ops, M, N, K, splits):
     """C = A^T B from row-major [K,M], [K,N] bf16 (ds_read_b64_tr_b16 fragments); asymmetric random operands."""
     from spectre_vit import _native
@@ -192,6 +195,36 @@ def test_gemm_tn(ops, M, N, K, splits):
     _native.call("spv_gemm_tn", A2.data_ptr(), B2.data_ptr(), C2.data_ptr(), 32, 40, Kp, 32, 40, 40, 0, 0, 1, 0,
                  torch.cuda.current_stream().cuda_stream)
     assert np.array_equal(n64(C2), bb[:32]), "A = I must return B's rows exactly"
+
+
+@pytest.mark.parametrize("shapes,rows,short_rows,splits", [([(768, 512), (512, 768)] * 2, 8320, 320, 7),   # the 256 x 128 tile
+                                                           ([(264, 136), (128, 128), (136, 264)], 2100, 130, 3)])   # the 128 x 128 tile, edges
+def test_gemm_tn_batch_long_and_short_problems(ops, shapes, rows, short_rows, splits):
+    """spv_gemm_tn_batch: several weight gradients in one launch -- the LONG ones over the call's K rows (split-K + reduce), the last
+    two as SHORT problems over their first `k` rows only (spv_tn_problem.k; the CLS-only last layer's gradients ride like this),
+    each against A^T B in float64."""
+    import ctypes
+    from spectre_vit import _native
+    rng = np.random.default_rng(rows + short_rows)
+    nshort = 2
+    A = [t(q(rng.standard_normal((rows, m)), torch.bfloat16), torch.bfloat16) for m, n in shapes]
+    B = [t(q(rng.standard_normal((rows, n)) + 0.25, torch.bfloat16), torch.bfloat16) for m, n in shapes]
+    C = [torch.full((m, n), 7.0, dtype=torch.float32, device=dev()) for m, n in shapes]
+    probs = (_native.TnProblem * len(shapes))()
+    for i, (pq, a, b, c, (m, n)) in enumerate(zip(probs, A, B, C, shapes)):
+        pq.a, pq.b, pq.c, pq.m, pq.n, pq.lda, pq.ldb, pq.ldc = a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, m, n, n
+        pq.k = short_rows if i >= len(shapes) - nshort else 0
+    floats = sum(m * n for m, n in shapes[:len(shapes) - nshort])
+    ws = torch.empty((splits * floats,), dtype=torch.float32, device=dev())
+    _native.call("spv_gemm_tn_batch", ctypes.addressof(probs), len(shapes), rows, splits, ws.data_ptr(), 0, 0,
+                 torch.cuda.current_stream().cuda_stream)
+    for i, (a, b, c) in enumerate(zip(A, B, C)):
+        r = short_rows if i >= len(shapes) - nshort else rows
+        check(c, n64(a)[:r].T @ n64(b)[:r], 1e-4, f"tn batch problem {i} ({r} rows)")
+    with pytest.raises(RuntimeError):   # a problem may not reduce over MORE rows than the call
+        probs[0].k = rows + 64
+        _native.call("spv_gemm_tn_batch", ctypes.addressof(probs), len(shapes), rows, splits, ws.data_ptr(), 0, 0,
+                     torch.cuda.current_stream().cuda_stream)
 
 
 def test_gemm_grouped_rows(ops):

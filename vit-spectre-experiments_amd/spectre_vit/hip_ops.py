@@ -669,10 +669,9 @@ def _weight_grad(dh, x, rows, n, k, sink=None, fold=None, fold_sunk=False):
     splits = max(1, min(512 // tiles, (rows + 511) // 512 if tiles >= 8 else (rows + 63) // 64))
     if tiles < 8:
         splits = min(splits, 64)  # the patch-embedding gradient (512 x 48): 128 slices made the reduce (10 us) as long as the GEMM
-    elif n % 256 == 0 and k % 128 == 0 and 4 <= 512 // ((n // 256) * (k // 128)) <= rows // 2048:
-        # the 256 x 128 tile (one 8-wave workgroup per CU, taken by spv_gemm_tn from 4 slices up): two dispatch rounds of it.  The
-        # MHPermutMix gradient [512, 8192, 33280]: 320 us at 4 slices against 348 at 2 slices of the 128 x 128 tile (same box)
-        splits = 512 // ((n // 256) * (k // 128))
+    # (The 256 x 128 tile at 4 slices is 8 % faster on the MHPermutMix gradient [512, 8192, 33280] in isolation -- 320 against 348 us --
+    # and SLOWER where it runs, on the side stream beside the data-gradient GEMM and the inverse gather: 701 against ~500 us, step 5.92
+    # -> 6.25 ms.  Its 112 KB of LDS per workgroup leave those kernels less of every CU than the 128 x 128 tile's 40 KB.)
     if _TN_DMA and n % 128 == 0 and k % 128 == 0 and rows % 64 == 0 and dh.dtype == torch.bfloat16:
         # the LDS-DMA kernel (spv_gemm.hip gemm_tn_dma_kernel; opt-in, SPV_TN_DMA=1) runs ONE 8-wave workgroup per CU: one dispatch
         # round of <= 256 workgroups (24 tiles x 10 K-slices of 52 K-tiles at the layer shapes)
