@@ -451,6 +451,8 @@ FOLD_RIDE = not _lab("SPV_NO_FOLD_RIDE", "")    # tail folds ride in their layer
 # step that exchanges its gradients in ONE call after the backward pass (spectre_vit.graph.GraphedDPStep) has no such need and
 # sets this flag while its backward passes run.
 HOLD_UNDER_DP = False
+WGRAD_PER_LAYER = _lab("SPV_WGRAD_PER_LAYER", "0") == "1"   # lab: each layer's two weight gradients as their own side-stream batch, started when
+# that layer's backward is done (operands still in the Infinity Cache) instead of one batch at the end of the pass
 FOLDS_BESIDE_BATCH = False   # True: start_held_wgrads issues the held folds as their own launch on the main stream, beside the batch,
 # instead of as extra workgroups of its reduce.  Measured (round 3): the reduce drops 29 -> 17 us, but the 68-us fold launch then
 # stands in front of the embedding's backward on the main stream, which becomes the longer chain: window 251 -> 266 us.  Off.
@@ -1650,6 +1652,8 @@ class FNetResidualFn(torch.autograd.Function):
     def backward(ctx, dout):
         sn = ctx.saved
         B, N, D = ctx.shape
+        if WGRAD_PER_LAYER:
+            start_held_wgrads()   # this layer's two weight gradients (held by the feed-forward half's backward, just done): side stream
         d2 = dout.reshape(-1, D)
         if not d2.is_contiguous():
             d2 = d2.contiguous()
