@@ -493,7 +493,20 @@ __global__ __launch_bounds__(512) void gemm_nt_strip_kernel(const bf16_t* __rest
     const int wm = wave >> 2, wn = wave & 3;
     // the strips of one row group sit on one XCD and run together: its A rows are fetched into that L2 once
     const int id = xcd_remap(blockIdx.x, nwg);
-    const int g = id / nstrips, strip = id % nstrips;
+    int g = id / nstrips, strip = id % nstrips;
+    // MANY strips (the MHPermutMix data gradient, N = 8192: 32): a whole row group per XCD means 32 different B strips of 256 x K each
+    // on its 32 CUs -- 8 MB at K = 512 through a 4 MB L2, re-read for every sub-tile: PMC 1.14 GB fetched per launch against 42 MB of
+    // operands.  So an XCD takes 8 strips x (its workgroups / 8) row groups instead: 2 MB of B that stays, A fetched by four XCDs.
+    {
+        const int per_xcd = nwg >> 3, groups = nwg / nstrips;
+        constexpr int S = 8;
+        if (nstrips >= 16 && (nwg & 7) == 0 && nstrips % S == 0 && per_xcd % S == 0 && groups % (per_xcd / S) == 0) {
+            const int G = per_xcd / S, SS = nstrips / S;
+            const int x = id / per_xcd, local = id % per_xcd;
+            strip = (x % SS) * S + local % S;
+            g = (x / SS) * G + local / S;
+        }
+    }
     int blk0 = g * base + min(g, rem);
     int cnt = base + (g < rem ? 1 : 0);
     const int n0 = strip * 256;
