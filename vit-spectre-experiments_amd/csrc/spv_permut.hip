@@ -137,6 +137,119 @@ __global__ __launch_bounds__(256) void gather_fwd_global_kernel(const T* __restr
     }
 }
 
+// Rows that do not fit the LDS (Spectre-ViT-Base at 224 / 16: d = 197 x 768 = 151 296 bf16 = 296 KB) in PARTS that do: a workgroup owns
+// PARTS_CH gathered elements, keeps their table entries in registers, and for each part of the sample's row -- staged in LDS
+// by coalesced 16-byte loads -- picks up the elements whose source lies in it.  The row is read from L2 once per workgroup instead of
+// being hit by one random two-byte global load per element (gather_fwd_global_kernel: 592 us per Base layer at bs 64, 12 of the
+// student step's 30 ms together with the backward below).  grid = (chunks of PARTS_CH elements, batch).
+constexpr int PARTS_T = 512;     // threads: 2 waves per SIMD, so that 64 table entries + values per thread stay in registers
+constexpr int PARTS_G = 8;       // groups of 8 CONSECUTIVE elements per thread (two 16-byte table loads, one 16-byte store per group)
+constexpr int PARTS_CH = PARTS_T * PARTS_G * 8;   // elements per workgroup: 32 768
+typedef unsigned gp_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int PARTS_GF = 8;      // the forward: 8 groups per thread too (12 and 16 spill: 48 / 168 VGPRs)
+constexpr int PARTS_CHF = PARTS_T * PARTS_GF * 8;
+__global__ __launch_bounds__(PARTS_T) void gather_fwd_parts_kernel(const uint16_t* __restrict__ x, const uint32_t* __restrict__ idx,
+                                                                   uint16_t* __restrict__ g, int heads, int d, int part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gp_smem[];
+    const uint16_t* row = reinterpret_cast<const uint16_t*>(gp_smem);
+    const int b = blockIdx.y;
+    const int total = heads * d;   // < 2^31 (host), a multiple of 8
+    const int f0 = blockIdx.x * PARTS_CHF + threadIdx.x * 8;   // group gi starts at f0 + gi * PARTS_T * 8
+    const uint16_t* xr = x + (size_t)b * d;
+    gp_u32x4 id[PARTS_GF][2], out[PARTS_GF];
+#pragma unroll
+    for (int gi = 0; gi < PARTS_GF; ++gi) {
+        const int f = f0 + gi * PARTS_T * 8;
+        const bool in = f < total;
+        id[gi][0] = in ? *reinterpret_cast<const gp_u32x4*>(idx + f) : gp_u32x4{~0u, ~0u, ~0u, ~0u};   // (an index that lies in no part)
+        id[gi][1] = in ? *reinterpret_cast<const gp_u32x4*>(idx + f + 4) : gp_u32x4{~0u, ~0u, ~0u, ~0u};
+        out[gi] = gp_u32x4{0u, 0u, 0u, 0u};
+    }
+    for (int base = 0; base < d; base += part) {
+        const int len = min(part, d - base);   // multiples of 8 (host)
+        for (int p = threadIdx.x * 8; p < len; p += PARTS_T * 8)
+            *reinterpret_cast<gp_u32x4*>(gp_smem + (size_t)p * 2) = *reinterpret_cast<const gp_u32x4*>(xr + base + p);
+        __syncthreads();
+#pragma unroll
+        for (int gi = 0; gi < PARTS_GF; ++gi)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t w = id[gi][e >> 2][e & 3];
+                const uint32_t pos = (w & 0x7fffffffu) - (uint32_t)base;
+                if (pos < (uint32_t)len) {
+                    const uint32_t v = (uint32_t)row[pos] ^ ((w >> 31) << 15);
+                    out[gi][e >> 1] |= v << (16 * (e & 1));
+                }
+            }
+        __syncthreads();
+    }
+    uint16_t* go = g + (size_t)b * total;
+#pragma unroll
+    for (int gi = 0; gi < PARTS_GF; ++gi) {
+        const int f = f0 + gi * PARTS_T * 8;
+        if (f < total) *reinterpret_cast<gp_u32x4*>(go + f) = out[gi];
+    }
+}
+// backward: dx[b][i] = sum_h +-dg[b][h][inv_h(i)], heads in ascending order in fp32 (the order of gather_bwd_global_kernel): a workgroup
+// owns PARTS_CH inputs and walks (head, part of that head's gradient row).  grid = (chunks of inputs, batch).
+__global__ __launch_bounds__(PARTS_T) void gather_bwd_parts_kernel(const bf16_t* __restrict__ dg, const uint32_t* __restrict__ inv,
+                                                                   bf16_t* __restrict__ dx, int heads, int d, int part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gpb_smem[];
+    const bf16_t* row = reinterpret_cast<const bf16_t*>(gpb_smem);
+    const int b = blockIdx.y;
+    const int i0 = blockIdx.x * PARTS_CH + threadIdx.x * 8;
+    float acc[PARTS_G][8];
+#pragma unroll
+    for (int gi = 0; gi < PARTS_G; ++gi)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[gi][e] = 0.0f;
+    for (int h = 0; h < heads; ++h) {
+        gp_u32x4 id[PARTS_G][2];
+#pragma unroll
+        for (int gi = 0; gi < PARTS_G; ++gi) {
+            const int i = i0 + gi * PARTS_T * 8;
+            const bool in = i < d;
+            id[gi][0] = in ? *reinterpret_cast<const gp_u32x4*>(inv + (size_t)h * d + i) : gp_u32x4{~0u, ~0u, ~0u, ~0u};
+            id[gi][1] = in ? *reinterpret_cast<const gp_u32x4*>(inv + (size_t)h * d + i + 4) : gp_u32x4{~0u, ~0u, ~0u, ~0u};
+        }
+        const bf16_t* src = dg + ((size_t)b * heads + h) * d;
+        for (int base = 0; base < d; base += part) {
+            const int len = min(part, d - base);
+            for (int p = threadIdx.x * 8; p < len; p += PARTS_T * 8)
+                *reinterpret_cast<gp_u32x4*>(gpb_smem + (size_t)p * 2) = *reinterpret_cast<const gp_u32x4*>(src + base + p);
+            __syncthreads();
+#pragma unroll
+            for (int gi = 0; gi < PARTS_G; ++gi)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t w = id[gi][e >> 2][e & 3];
+                    const uint32_t pos = (w & 0x7fffffffu) - (uint32_t)base;
+                    if (pos < (uint32_t)len) {
+                        const float v = bf2f(row[pos]);
+                        acc[gi][e] += (w >> 31) ? -v : v;
+                    }
+                }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int gi = 0; gi < PARTS_G; ++gi) {
+        const int i = i0 + gi * PARTS_T * 8;
+        if (i < d) {
+            gp_u32x4 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[u] = pack_bf16x2(acc[gi][2 * u], acc[gi][2 * u + 1]);
+            *reinterpret_cast<gp_u32x4*>(dx + (size_t)b * d + i) = o;
+        }
+    }
+}
+// part length for a row of d elements: the fewest equal parts that fit the LDS, a multiple of 8 elements
+inline int parts_len(int d) {
+    const int cap = LDS_LIMIT / 2;
+    const int n = (d + cap - 1) / cap;
+    return (((d + n - 1) / n) + 7) / 8 * 8;
+}
+
 // backward, LDS path: grid = batch; thread owns elements i = (it*PT + tid)*4 .. +3, it < MAX_IT
 constexpr int MAX_IT = 10;  // d <= 4 * PT * MAX_IT = 40 960
 template <typename T>
@@ -500,6 +613,12 @@ extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
             hipLaunchKernelGGL((gather_fwd_lds_kernel<float>), dim3(batch), dim3(PT), lds, st, (const float*)x, idx, (float*)g, heads, d, (float*)pooled, pool_window);
         }
+    } else if (dtype == SPV_BF16 && d % 8 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)idx) & 15) == 0 && (int64_t)heads * d < (1ll << 31) - PARTS_CHF) {
+        // rows longer than the LDS: staged part by part (Base / 224)
+        const int part = parts_len(d);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_parts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        const dim3 grid((unsigned)(((int64_t)heads * d + PARTS_CHF - 1) / PARTS_CHF), batch);
+        hipLaunchKernelGGL(gather_fwd_parts_kernel, grid, dim3(PARTS_T), (size_t)part * 2, st, (const uint16_t*)x, idx, (uint16_t*)g, heads, d, part);
     } else {
         dim3 grid((unsigned)std::min<int64_t>(((int64_t)heads * d + 255) / 256, 1024), batch);
         if (dtype == SPV_BF16)
@@ -540,6 +659,15 @@ extern "C" int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* 
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_bwd_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
             hipLaunchKernelGGL((gather_bwd_lds_kernel<float>), dim3(batch), dim3(PT), lds, st, (const float*)dg, inv, (float*)dx, heads, d);
         }
+    } else if (!SPV_LAB_SET("SPV_GATHER_BWD_GLOBAL") && dtype == SPV_BF16 && d % 8 == 0 && (((uintptr_t)dg | (uintptr_t)dx | (uintptr_t)inv) & 15) == 0) {
+        // each of a sample's `heads` gradient rows serves only d lookups (the forward's ONE row serves heads x d), so a workgroup stages
+        // heads x parts = 24 parts of 151 KB for its 32 768 results: 581 us per Base layer where the global path measures 438 in the
+        // kernel statistics -- and still the better step (same job, alternating: 27.73 / 27.88 against 28.17 / 28.28 ms), because it
+        // leaves the L2 to the weight-gradient GEMM it runs beside
+        const int part = parts_len(d);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_bwd_parts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        const dim3 grid((unsigned)((d + PARTS_CH - 1) / PARTS_CH), batch);
+        hipLaunchKernelGGL(gather_bwd_parts_kernel, grid, dim3(PARTS_T), (size_t)part * 2, st, (const bf16_t*)dg, inv, (bf16_t*)dx, heads, d, part);
     } else {
         dim3 grid((unsigned)std::min((d + 255) / 256, 1024), batch);
         if (dtype == SPV_BF16)
