@@ -420,7 +420,8 @@ def test_add_layernorm(ops, dtype, mode, rows, n):
 
 # ------------------------------------------------------------------------------------------------ permutation gather
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,N,E,H", [(3, 5, 8, 3), (2, 65, 64, 4), (2, 65, 512, 16), (2, 100, 512, 2), (2, 7, 12, 5)])
+@pytest.mark.parametrize("B,N,E,H", [(3, 5, 8, 3), (2, 65, 64, 4), (2, 65, 512, 16), (2, 100, 512, 2), (2, 7, 12, 5),
+                                     (2, 197, 768, 2), (3, 160, 512, 3)])   # rows longer than the LDS (Base / 224): staged in parts (bf16)
 def test_permut_gather(ops, dtype, B, N, E, H):
     rng = np.random.default_rng(B + N + E + H)
     d = N * E
