@@ -243,6 +243,127 @@ __global__ __launch_bounds__(PARTS_T) void gather_bwd_parts_kernel(const bf16_t*
         }
     }
 }
+// ---- backward for rows longer than the LDS, as a SCATTER into output parts (round 3).  dx[b][perm_h(j)] += +-dg[b][h][j]: a workgroup
+// owns one part of a sample's dx as fp32 accumulators in LDS (d / 4 of them at Base / 224) and, head after head, adds the sources whose
+// target lies in its part -- listed at pack time per (head, part) in ascending source order, so the gradient row is read in (sparse)
+// sequence instead of by one random two-byte load per element, and every source is read exactly once per launch.  Within a head the
+// targets are distinct (a permutation): no atomics; heads are separated by a barrier and added in ascending order, as everywhere else.
+// Table tail (uint32 words behind the wide + compact tables): off [heads][nparts + 1], cur [heads][nparts] (pack-time cursors),
+// ej [heads][d] = source | sign << 31, et [heads][d] uint16 = target - part * L.
+inline bool long_row(int d) { return (size_t)d * 2 > (size_t)LDS_LIMIT; }
+inline int scat_parts(int d) { return (int)(((size_t)d * 4 + LDS_LIMIT - 1) / LDS_LIMIT); }
+inline int scat_len(int d) { const int n = scat_parts(d); return (((d + n - 1) / n) + 7) / 8 * 8; }
+inline int64_t scat_words(int heads, int d) {
+    const int64_t total = (int64_t)heads * d;
+    return (int64_t)heads * (scat_parts(d) + 1) + (int64_t)heads * scat_parts(d) + total + (total + 1) / 2;
+}
+struct ScatTail {
+    int* off;
+    int* cur;
+    uint32_t* ej;
+    uint16_t* et;
+};
+inline ScatTail scat_of(uint32_t* tail, int heads, int d) {
+    ScatTail t;
+    const int np = scat_parts(d);
+    t.off = reinterpret_cast<int*>(tail);
+    t.cur = t.off + (size_t)heads * (np + 1);
+    t.ej = reinterpret_cast<uint32_t*>(t.cur + (size_t)heads * np);
+    t.et = reinterpret_cast<uint16_t*>(t.ej + (size_t)heads * d);
+    return t;
+}
+__global__ __launch_bounds__(256) void scat_count_kernel(const uint32_t* __restrict__ fwd, int* __restrict__ cur, int heads, int d, int L, int np) {
+    // one wave per 64 consecutive sources of a head, one atomic per (wave, part) (a lane each: 1.8 M atomics on 48 counters took 5 ms)
+    const int lane = threadIdx.x & 63;
+    const int waves_per_head = (d + 63) / 64;
+    const int64_t nw = (int64_t)heads * waves_per_head;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nw; w += (int64_t)gridDim.x * 4) {
+        const int h = (int)(w / waves_per_head), j = (int)(w % waves_per_head) * 64 + lane;
+        const int q = j < d ? (int)((fwd[(size_t)h * d + j] & 0x7fffffffu) / (unsigned)L) : -1;
+        for (int p = 0; p < np; ++p) {
+            const unsigned long long m = __ballot(q == p);
+            if (m != 0ull && lane == __ffsll((long long)m) - 1) atomicAdd(&cur[h * np + p], __popcll(m));
+        }
+    }
+}
+__global__ void scat_prefix_kernel(int* __restrict__ off, int* __restrict__ cur, int heads, int np) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= heads) return;
+    int run = 0;
+    for (int q = 0; q < np; ++q) {
+        off[h * (np + 1) + q] = run;
+        const int c = cur[h * np + q];
+        cur[h * np + q] = run;   // the placement's cursor
+        run += c;
+    }
+    off[h * (np + 1) + np] = run;
+}
+// one wave per 64 consecutive sources of a head: each part's lanes take consecutive slots (ascending inside the wave; waves of a head
+// land in the order their atomics arrive -- any order gives the same sums, ascending-ish keeps the backward's reads sequential)
+__global__ __launch_bounds__(256) void scat_place_kernel(const uint32_t* __restrict__ fwd, int* __restrict__ cur, uint32_t* __restrict__ ej,
+                                                         uint16_t* __restrict__ et, int heads, int d, int L, int np) {
+    const int lane = threadIdx.x & 63;
+    const int waves_per_head = (d + 63) / 64;
+    const int64_t nw = (int64_t)heads * waves_per_head;
+    for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nw; w += (int64_t)gridDim.x * 4) {
+        const int h = (int)(w / waves_per_head), j = (int)(w % waves_per_head) * 64 + lane;
+        const bool in = j < d;
+        const uint32_t e = in ? fwd[(size_t)h * d + j] : 0u;
+        const unsigned tgt = e & 0x7fffffffu;
+        const int q = in ? (int)(tgt / (unsigned)L) : -1;
+        for (int p = 0; p < np; ++p) {
+            const unsigned long long m = __ballot(q == p);
+            if (m == 0ull) continue;
+            int base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&cur[h * np + p], __popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (q == p) {
+                const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                ej[(size_t)h * d + slot] = (uint32_t)j | (e & 0x80000000u);
+                et[(size_t)h * d + slot] = (uint16_t)(tgt - (unsigned)p * (unsigned)L);
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(1024) void gather_bwd_scatter_kernel(const bf16_t* __restrict__ dg, const int* __restrict__ off, const uint32_t* __restrict__ ej,
+                                                                  const uint16_t* __restrict__ et, bf16_t* __restrict__ dx, int heads, int d, int L,
+                                                                  int np) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
+    float* acc = reinterpret_cast<float*>(gs_smem);
+    const int q = blockIdx.x, b = blockIdx.y;
+    const int len = min(L, d - q * L);
+    for (int t = threadIdx.x; t < len; t += 1024) acc[t] = 0.0f;
+    __syncthreads();
+    for (int h = 0; h < heads; ++h) {
+        const int e0 = off[h * (np + 1) + q], e1 = off[h * (np + 1) + q + 1];
+        const bf16_t* src = dg + ((size_t)b * heads + h) * d;
+        const uint32_t* ejh = ej + (size_t)h * d;
+        const uint16_t* eth = et + (size_t)h * d;
+        int e = e0 + threadIdx.x;
+        for (; e + 3 * 1024 < e1; e += 4 * 1024) {   // four independent (entry, source) load pairs in flight per thread
+            uint32_t w[4];
+            unsigned t[4];
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { w[u] = ejh[e + u * 1024]; t[u] = eth[e + u * 1024]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = bf2f(src[w[u] & 0x7fffffffu]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[t[u]] += (w[u] >> 31) ? -v[u] : v[u];
+        }
+        for (; e < e1; e += 1024) {
+            const uint32_t w = ejh[e];
+            const float v = bf2f(src[w & 0x7fffffffu]);
+            acc[eth[e]] += (w >> 31) ? -v : v;
+        }
+        __syncthreads();
+    }
+    bf16_t* o = dx + (size_t)b * d + (size_t)q * L;
+    for (int t = threadIdx.x * 2; t < len; t += 2048) {   // len is even (multiple of 8)
+        *reinterpret_cast<unsigned*>(o + t) = pack_bf16x2(acc[t], acc[t + 1]);
+    }
+}
+
 // part length for a row of d elements: the fewest equal parts that fit the LDS, a multiple of 8 elements
 inline int parts_len(int d) {
     const int cap = LDS_LIMIT / 2;
@@ -572,12 +693,24 @@ extern "C" int spv_permut_pack(const int64_t* perms, const float* signs, uint32_
         hipLaunchKernelGGL(permut_compact_kernel, cg, dim3(256), 0, st, idx + total, const_cast<uint16_t*>(c.inv16), const_cast<uint8_t*>(c.inv_sg), octets);
         SPV_LAUNCH_CHECK("spv_permut_pack(compact)");
     }
+    if (long_row(d)) {   // the backward's scatter lists (rows longer than the LDS)
+        SPV_CHECK(scat_len(d) <= 65536, "spv_permut_pack: d=%d: a part of %d targets does not fit the 16-bit target table", d, scat_len(d));
+        uint32_t* tail = idx + (spv_permut_table_words(heads, d) - scat_words(heads, d));
+        const ScatTail t = scat_of(tail, heads, d);
+        const int np = scat_parts(d), L = scat_len(d);
+        (void)hipMemsetAsync(t.cur, 0, (size_t)heads * np * sizeof(int), st);
+        const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(scat_count_kernel, dim3(blocks), dim3(256), 0, st, idx, t.cur, heads, d, L, np);
+        hipLaunchKernelGGL(scat_prefix_kernel, dim3((heads + 63) / 64), dim3(64), 0, st, t.off, t.cur, heads, np);
+        hipLaunchKernelGGL(scat_place_kernel, dim3(blocks), dim3(256), 0, st, idx, t.cur, t.ej, t.et, heads, d, L, np);
+        SPV_LAUNCH_CHECK("spv_permut_pack(scatter lists)");
+    }
     return 0;
 }
 
 extern "C" int64_t spv_permut_table_words(int heads, int d) {
     const int64_t total = (int64_t)heads * d;
-    return 2 * total + (compact_ok(d) ? total + (total / 4 + 3) / 4 : 0);
+    return 2 * total + (compact_ok(d) ? total + (total / 4 + 3) / 4 : 0) + (long_row(d) ? scat_words(heads, d) : 0);
 }
 
 extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g, void* pooled, int pool_window, int batch,
@@ -659,6 +792,13 @@ extern "C" int spv_permut_gather_bwd(const void* dg, const uint32_t* idx, void* 
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_bwd_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
             hipLaunchKernelGGL((gather_bwd_lds_kernel<float>), dim3(batch), dim3(PT), lds, st, (const float*)dg, inv, (float*)dx, heads, d);
         }
+    } else if (!SPV_LAB_SET("SPV_GATHER_BWD_PARTS") && dtype == SPV_BF16 && long_row(d) && d % 8 == 0 && (size_t)scat_len(d) * 4 <= (size_t)LDS_LIMIT) {
+        // the scatter into output parts (lists built by spv_permut_pack behind the other tables)
+        const ScatTail t = scat_of(const_cast<uint32_t*>(idx) + (spv_permut_table_words(heads, d) - scat_words(heads, d)), heads, d);
+        const int np = scat_parts(d), L = scat_len(d);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_bwd_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        hipLaunchKernelGGL(gather_bwd_scatter_kernel, dim3(np, batch), dim3(1024), (size_t)L * 4, st, (const bf16_t*)dg, t.off, t.ej, t.et, (bf16_t*)dx, heads, d, L,
+                           np);
     } else if (!SPV_LAB_SET("SPV_GATHER_BWD_GLOBAL") && dtype == SPV_BF16 && d % 8 == 0 && (((uintptr_t)dg | (uintptr_t)dx | (uintptr_t)inv) & 15) == 0) {
         // each of a sample's `heads` gradient rows serves only d lookups (the forward's ONE row serves heads x d), so a workgroup stages
         // heads x parts = 24 parts of 151 KB for its 32 768 results: 581 us per Base layer where the global path measures 438 in the
