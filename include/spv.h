@@ -224,8 +224,9 @@ int spv_add_layernorm_bwd(const void* dout, const void* a, const void* b, const 
 /* idx: spv_permut_table_words(heads, d) uint32 words, opaque to the caller: the wide tables uint32 [2][heads][d] -- [0] forward
  * (perm | sign), [1] inverse (inverse perm | sign) -- followed, when d <= 65 536 and d % 8 == 0, by their compact form (uint16
  * indices + one sign bit per element) which the bf16 kernels read instead: every workgroup walks the whole table, so its
- * width is L2 traffic; and, when a bf16 row of d elements does not fit the LDS (Spectre-ViT-Base at 224 / 16), by the backward's
- * scatter lists: per (head, quarter of the output row) the sources whose target lies in that quarter, in ascending order. */
+ * width is L2 traffic; and, when a bf16 row of d elements does not fit the LDS (Spectre-ViT-Base at 224 / 16), by two sets
+ * of scatter lists (backward and forward): per (head, quarter of the output row) the sources whose target lies in that quarter, in
+ * ascending order. */
 int64_t spv_permut_table_words(int heads, int d);
 int spv_permut_pack(const int64_t* perms, const float* signs, uint32_t* idx, int heads, int d, void* stream);
 /* pooled (nullable, [batch, heads*d / pool_window]): the average of every pool_window consecutive gathered elements

@@ -248,15 +248,17 @@ __global__ __launch_bounds__(PARTS_T) void gather_bwd_parts_kernel(const bf16_t*
 // target lies in its part -- listed at pack time per (head, part) in ascending source order, so the gradient row is read in (sparse)
 // sequence instead of by one random two-byte load per element, and every source is read exactly once per launch.  Within a head the
 // targets are distinct (a permutation): no atomics; heads are separated by a barrier and added in ascending order, as everywhere else.
-// Table tail (uint32 words behind the wide + compact tables): off [heads][nparts + 1], cur [heads][nparts] (pack-time cursors),
+// Table tail (uint32 words behind the wide + compact tables), two sets -- [0] from the forward table for this backward, [1] from the
+// inverse table for the forward below --, each: off [heads][nparts + 1], cur [heads][nparts] (pack-time cursors),
 // ej [heads][d] = source | sign << 31, et [heads][d] uint16 = target - part * L.
 inline bool long_row(int d) { return (size_t)d * 2 > (size_t)LDS_LIMIT; }
 inline int scat_parts(int d) { return (int)(((size_t)d * 4 + LDS_LIMIT - 1) / LDS_LIMIT); }
 inline int scat_len(int d) { const int n = scat_parts(d); return (((d + n - 1) / n) + 7) / 8 * 8; }
-inline int64_t scat_words(int heads, int d) {
+inline int64_t scat_set_words(int heads, int d) {   // one list set
     const int64_t total = (int64_t)heads * d;
     return (int64_t)heads * (scat_parts(d) + 1) + (int64_t)heads * scat_parts(d) + total + (total + 1) / 2;
 }
+inline int64_t scat_words(int heads, int d) { return 2 * scat_set_words(heads, d); }   // [0] the backward's (from the forward table), [1] the forward's
 struct ScatTail {
     int* off;
     int* cur;
@@ -362,6 +364,41 @@ __global__ __launch_bounds__(1024) void gather_bwd_scatter_kernel(const bf16_t* 
     for (int t = threadIdx.x * 2; t < len; t += 2048) {   // len is even (multiple of 8)
         *reinterpret_cast<unsigned*>(o + t) = pack_bf16x2(acc[t], acc[t + 1]);
     }
+}
+
+// the forward the same way round: g[b][h][inv_h(i)] = +-x[b][i].  A workgroup owns one quarter of ONE head's output row in LDS (bf16,
+// 74 KB: two workgroups per CU), fills it from the (head, quarter) list of the INVERSE table -- the sample's row is read in sparse
+// sequence, every slot is written exactly once -- and stores it in whole 16-byte pieces.  grid = (parts, heads, batch).
+__global__ __launch_bounds__(1024) void gather_fwd_scatter_kernel(const uint16_t* __restrict__ x, const int* __restrict__ off, const uint32_t* __restrict__ ej,
+                                                                  const uint16_t* __restrict__ et, uint16_t* __restrict__ g, int heads, int d, int L,
+                                                                  int np) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gfs_smem[];
+    uint16_t* out = reinterpret_cast<uint16_t*>(gfs_smem);
+    const int q = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = min(L, d - q * L);
+    const int e0 = off[h * (np + 1) + q], e1 = off[h * (np + 1) + q + 1];
+    const uint16_t* src = x + (size_t)b * d;
+    const uint32_t* ejh = ej + (size_t)h * d;
+    const uint16_t* eth = et + (size_t)h * d;
+    int e = e0 + threadIdx.x;
+    for (; e + 3 * 1024 < e1; e += 4 * 1024) {
+        uint32_t w[4];
+        unsigned t[4];
+        uint16_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { w[u] = ejh[e + u * 1024]; t[u] = eth[e + u * 1024]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[w[u] & 0x7fffffffu];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[t[u]] = v[u] ^ (uint16_t)((w[u] >> 31) << 15);
+    }
+    for (; e < e1; e += 1024) {
+        const uint32_t w = ejh[e];
+        out[eth[e]] = src[w & 0x7fffffffu] ^ (uint16_t)((w >> 31) << 15);
+    }
+    __syncthreads();
+    uint16_t* o = g + ((size_t)b * heads + h) * d + (size_t)q * L;
+    for (int t = threadIdx.x * 8; t < len; t += 1024 * 8) *reinterpret_cast<uint4*>(o + t) = *reinterpret_cast<const uint4*>(out + t);
 }
 
 // part length for a row of d elements: the fewest equal parts that fit the LDS, a multiple of 8 elements
@@ -696,13 +733,16 @@ extern "C" int spv_permut_pack(const int64_t* perms, const float* signs, uint32_
     if (long_row(d)) {   // the backward's scatter lists (rows longer than the LDS)
         SPV_CHECK(scat_len(d) <= 65536, "spv_permut_pack: d=%d: a part of %d targets does not fit the 16-bit target table", d, scat_len(d));
         uint32_t* tail = idx + (spv_permut_table_words(heads, d) - scat_words(heads, d));
-        const ScatTail t = scat_of(tail, heads, d);
         const int np = scat_parts(d), L = scat_len(d);
-        (void)hipMemsetAsync(t.cur, 0, (size_t)heads * np * sizeof(int), st);
         const int blocks = (int)std::min<int64_t>((total + 255) / 256, 2048);
-        hipLaunchKernelGGL(scat_count_kernel, dim3(blocks), dim3(256), 0, st, idx, t.cur, heads, d, L, np);
-        hipLaunchKernelGGL(scat_prefix_kernel, dim3((heads + 63) / 64), dim3(64), 0, st, t.off, t.cur, heads, np);
-        hipLaunchKernelGGL(scat_place_kernel, dim3(blocks), dim3(256), 0, st, idx, t.cur, t.ej, t.et, heads, d, L, np);
+        for (int set = 0; set < 2; ++set) {   // [0]: targets of the forward table (the backward's lists); [1]: of the inverse table
+            const ScatTail t = scat_of(tail + set * scat_set_words(heads, d), heads, d);
+            const uint32_t* table = idx + (size_t)set * total;
+            (void)hipMemsetAsync(t.cur, 0, (size_t)heads * np * sizeof(int), st);
+            hipLaunchKernelGGL(scat_count_kernel, dim3(blocks), dim3(256), 0, st, table, t.cur, heads, d, L, np);
+            hipLaunchKernelGGL(scat_prefix_kernel, dim3((heads + 63) / 64), dim3(64), 0, st, t.off, t.cur, heads, np);
+            hipLaunchKernelGGL(scat_place_kernel, dim3(blocks), dim3(256), 0, st, table, t.cur, t.ej, t.et, heads, d, L, np);
+        }
         SPV_LAUNCH_CHECK("spv_permut_pack(scatter lists)");
     }
     return 0;
@@ -746,6 +786,14 @@ extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
             hipLaunchKernelGGL((gather_fwd_lds_kernel<float>), dim3(batch), dim3(PT), lds, st, (const float*)x, idx, (float*)g, heads, d, (float*)pooled, pool_window);
         }
+    } else if (!SPV_LAB_SET("SPV_GATHER_FWD_PARTS") && dtype == SPV_BF16 && long_row(d) && d % 8 == 0 && pooled == nullptr &&
+               (((uintptr_t)x | (uintptr_t)g) & 15) == 0 && heads <= 65535 && batch <= 65535) {
+        // output quarters in LDS, filled from the inverse table's lists (spv_permut_pack)
+        const ScatTail t = scat_of(const_cast<uint32_t*>(idx) + (spv_permut_table_words(heads, d) - scat_words(heads, d)) + scat_set_words(heads, d), heads, d);
+        const int np = scat_parts(d), L = scat_len(d);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
+        hipLaunchKernelGGL(gather_fwd_scatter_kernel, dim3(np, heads, batch), dim3(1024), (size_t)L * 2, st, (const uint16_t*)x, t.off, t.ej, t.et, (uint16_t*)g, heads,
+                           d, L, np);
     } else if (dtype == SPV_BF16 && d % 8 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)idx) & 15) == 0 && (int64_t)heads * d < (1ll << 31) - PARTS_CHF) {
         // rows longer than the LDS: staged part by part (Base / 224)
         const int part = parts_len(d);
