@@ -228,6 +228,8 @@ int spv_add_layernorm_bwd(const void* dout, const void* a, const void* b, const 
  * of scatter lists (backward and forward): per (head, quarter of the output row) the sources whose target lies in that quarter, in
  * ascending order. */
 int64_t spv_permut_table_words(int heads, int d);
+/* 1 when spv_permut_gather_fwd emits `pooled` for this window on rows longer than the LDS (any window that divides d and a quarter of it) */
+int spv_permut_pool_supported(int heads, int d, int pool_window, int dtype);
 int spv_permut_pack(const int64_t* perms, const float* signs, uint32_t* idx, int heads, int d, void* stream);
 /* pooled (nullable, [batch, heads*d / pool_window]): the average of every pool_window consecutive gathered elements
  * (what the SpectreLinear skip needs), produced on the fly so the tail kernel does not re-read g. */

@@ -371,7 +371,7 @@ __global__ __launch_bounds__(1024) void gather_bwd_scatter_kernel(const bf16_t* 
 // sequence, every slot is written exactly once -- and stores it in whole 16-byte pieces.  grid = (parts, heads, batch).
 __global__ __launch_bounds__(1024) void gather_fwd_scatter_kernel(const uint16_t* __restrict__ x, const int* __restrict__ off, const uint32_t* __restrict__ ej,
                                                                   const uint16_t* __restrict__ et, uint16_t* __restrict__ g, int heads, int d, int L,
-                                                                  int np) {
+                                                                  int np, bf16_t* __restrict__ pooled, int pw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gfs_smem[];
     uint16_t* out = reinterpret_cast<uint16_t*>(gfs_smem);
     const int q = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -399,6 +399,17 @@ __global__ __launch_bounds__(1024) void gather_fwd_scatter_kernel(const uint16_t
     __syncthreads();
     uint16_t* o = g + ((size_t)b * heads + h) * d + (size_t)q * L;
     for (int t = threadIdx.x * 8; t < len; t += 1024 * 8) *reinterpret_cast<uint4*>(o + t) = *reinterpret_cast<const uint4*>(out + t);
+    if (pooled != nullptr) {
+        // the SpectreLinear skip of the mix linear (AdaptiveAvgPool1d over every pw consecutive gathered elements; d and L are multiples of
+        // pw, so no window crosses this quarter): emitted here so that the tail does not re-read the gathered tensor (232 MB per Base layer)
+        bf16_t* po = pooled + (((size_t)b * heads + h) * d + (size_t)q * L) / pw;
+        const float inv = 1.0f / (float)pw;
+        for (int w = threadIdx.x; w < len / pw; w += 1024) {
+            float a = 0.0f;
+            for (int u = 0; u < pw; ++u) a += bf2f(out[w * pw + u]);
+            po[w] = f2bf(a * inv);
+        }
+    }
 }
 
 // part length for a row of d elements: the fewest equal parts that fit the LDS, a multiple of 8 elements
@@ -748,6 +759,13 @@ extern "C" int spv_permut_pack(const int64_t* perms, const float* signs, uint32_
     return 0;
 }
 
+/* 1 when spv_permut_gather_fwd can emit the pooled skip for this window on the long-row (scatter) path */
+extern "C" int spv_permut_pool_supported(int heads, int d, int pool_window, int dtype) {
+    (void)heads;
+    return (dtype == SPV_BF16 && long_row(d) && d % 8 == 0 && pool_window > 0 && d % pool_window == 0 && scat_len(d) % pool_window == 0 &&
+            !SPV_LAB_SET("SPV_GATHER_FWD_PARTS")) ? 1 : 0;
+}
+
 extern "C" int64_t spv_permut_table_words(int heads, int d) {
     const int64_t total = (int64_t)heads * d;
     return 2 * total + (compact_ok(d) ? total + (total / 4 + 3) / 4 : 0) + (long_row(d) ? scat_words(heads, d) : 0);
@@ -760,7 +778,9 @@ extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t es = dtype == SPV_BF16 ? 2 : 4;
     const bool aligned = ((size_t)d * es) % 16 == 0 && ((int64_t)heads * d) % 4 == 0;
-    if (pooled != nullptr) {
+    const bool scat_pool = pooled != nullptr && dtype == SPV_BF16 && long_row(d) && pool_window > 0 && d % pool_window == 0 &&
+                           scat_len(d) % pool_window == 0;   // the scatter path emits any window that divides its quarters
+    if (pooled != nullptr && !scat_pool) {
         const int64_t total = (int64_t)heads * d;
         SPV_CHECK(aligned && (size_t)d * es <= (size_t)LDS_LIMIT, "spv_permut_gather_fwd: pooled output needs the LDS path");
         SPV_CHECK((pool_window == 4 || pool_window == 8 || pool_window == 16 || pool_window == 32) && total % pool_window == 0 &&
@@ -786,14 +806,14 @@ extern "C" int spv_permut_gather_fwd(const void* x, const uint32_t* idx, void* g
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_lds_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
             hipLaunchKernelGGL((gather_fwd_lds_kernel<float>), dim3(batch), dim3(PT), lds, st, (const float*)x, idx, (float*)g, heads, d, (float*)pooled, pool_window);
         }
-    } else if (!SPV_LAB_SET("SPV_GATHER_FWD_PARTS") && dtype == SPV_BF16 && long_row(d) && d % 8 == 0 && pooled == nullptr &&
+    } else if (!SPV_LAB_SET("SPV_GATHER_FWD_PARTS") && dtype == SPV_BF16 && long_row(d) && d % 8 == 0 && (pooled == nullptr || scat_pool) &&
                (((uintptr_t)x | (uintptr_t)g) & 15) == 0 && heads <= 65535 && batch <= 65535) {
         // output quarters in LDS, filled from the inverse table's lists (spv_permut_pack)
         const ScatTail t = scat_of(const_cast<uint32_t*>(idx) + (spv_permut_table_words(heads, d) - scat_words(heads, d)) + scat_set_words(heads, d), heads, d);
         const int np = scat_parts(d), L = scat_len(d);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_fwd_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT);
         hipLaunchKernelGGL(gather_fwd_scatter_kernel, dim3(np, heads, batch), dim3(1024), (size_t)L * 2, st, (const uint16_t*)x, t.off, t.ej, t.et, (uint16_t*)g, heads,
-                           d, L, np);
+                           d, L, np, (bf16_t*)pooled, pool_window);
     } else if (dtype == SPV_BF16 && d % 8 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)idx) & 15) == 0 && (int64_t)heads * d < (1ll << 31) - PARTS_CHF) {
         // rows longer than the LDS: staged part by part (Base / 224)
         const int part = parts_len(d);

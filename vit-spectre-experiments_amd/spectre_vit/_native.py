@@ -52,6 +52,7 @@ SIGNATURES = {
     "spv_permut_row0_fwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_row0_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_vp],
     "spv_permut_table_words": [c_i, c_i],
+    "spv_permut_pool_supported": [c_i, c_i, c_i, c_i],
     "spv_tail_bwd_parts": [c_i],
     "spv_haar_ln_supported": [c_i, c_i],
     "spv_haar_ln_fwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
@@ -106,7 +107,7 @@ SIGNATURES = {
 _RESTYPES = {"spv_last_error": ctypes.c_char_p, "spv_path_count": ctypes.c_longlong, "spv_rowop_partial_floats": c_i64, "spv_fnet_workspace_floats": c_i64,
              "spv_fnet_twiddle_floats": c_i64, "spv_tail_ln_partial_floats": c_i64, "spv_permut_table_words": c_i64, "spv_small_sl_partial_floats": c_i64,
              "spv_cross_entropy_workspace_floats": c_i64}
-_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_fnet_cls_supported", "spv_tail_ln_supported", "spv_tail_up_supported", "spv_small_sl_supported", "spv_tail_bwd_parts", "spv_embed_bwd_groups", "spv_haar_ln_supported"}
+_NO_STATUS = set(_RESTYPES) | {"spv_version", "spv_fnet_ln_supported", "spv_fnet_cls_supported", "spv_tail_ln_supported", "spv_tail_up_supported", "spv_small_sl_supported", "spv_tail_bwd_parts", "spv_embed_bwd_groups", "spv_haar_ln_supported", "spv_permut_pool_supported"}
 
 class FoldJob(ctypes.Structure):
     """spv_fold_job (include/spv.h): the fold of a tail backward's partial column sums, handed to spv_gemm_tn_fold"""

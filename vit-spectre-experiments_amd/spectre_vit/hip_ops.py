@@ -1784,6 +1784,8 @@ class PermutMixFn(torch.autograd.Function):
         pw = k // n if k % n == 0 else 0
         es = 2 if dt == torch.bfloat16 else 4
         can_pool = pw in (4, 8, 16, 32) and (d * es) % 16 == 0 and d * es <= 150 * 1024 and (total // 4) % 1024 == 0 and total % pw == 0
+        if not can_pool and pw > 0 and total % pw == 0:   # rows longer than the LDS (Base / 224, window 12): the scatter gather pools too
+            can_pool = bool(_native.call("spv_permut_pool_supported", heads, d, pw, _dt(xc)))
         dev = xc.device
         g = torch.empty((rows, k), dtype=dt, device=dev)
         pooled = torch.empty((rows, n), dtype=dt, device=dev) if can_pool else None
