@@ -173,7 +173,9 @@ def test_gemm_nt_strip_kernel_with_reserved_cus(ops):
                                           (8, 16, 40, 1), (264, 136, 4100, 5),
                                           (768, 512, 8010, 12),    # the 256 x 128 tile with a partial last K-tile in the last slice
                                           (512, 48, 3000, 16),     # the sliver shape of the patch-embedding gradient (one K-tile in flight)
-                                          (256, 128, 100, 1)])     # fewer rows than one pipelined group of K-tiles
+                                          (256, 128, 100, 1),      # fewer rows than one pipelined group of K-tiles
+                                          (512, 8192, 2600, 3),    # the 512 x 128 tile (all of M in one workgroup), partial last K-tile
+                                          (512, 8192, 4000, 4)])
 def test_gemm_tn(ops, M, N, K, splits):
     """C = A^T B from row-major [K,M], [K,N] bf16 (ds_read_b64_tr_b16 fragments); asymmetric random operands."""
     from spectre_vit import _native

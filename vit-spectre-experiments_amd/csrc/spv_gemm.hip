@@ -1483,6 +1483,144 @@ __global__ __launch_bounds__(512) void gemm_tn_wide_kernel(const bf16_t* __restr
     tn_wide_body<TO, DB>(A, B, C, ws, M, N, K, lda, ldb, ldc, k_per_split, accumulate, tiles_n, lin % tiles_mn, lin / tiles_mn);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// TN contraction, TALL tile: 512 (m) x 128 (n) per 8-wave workgroup (waves 4 x 2, 128 x 64 each: 128 accumulator registers), 32-row
+// K-tiles, three register sets of operand rows, two LDS buffers, one barrier per K-tile.  For gradients with M = 512 and a long N -- the
+// MHPermutMix linear's [512, 8192, 33 280] --, where the 128 x 128 kernel's four row tiles of a column block are four workgroups that
+// each stream the same 8.5 MB panel of the gathered matrix and drift apart by more K-tiles than the L2 holds (PMC: 1.47 GB fetched per
+// launch against 0.58 GB of operands: the kernel ran at 4.2 TB/s of HBM).  Here ONE workgroup owns all of M: the panel is read once.
+constexpr int TTM = 512;
+constexpr int TTK = 32;
+constexpr int TTROWA = TTM * 2 + 64;   // 1088 = 64 mod 256: the four k rows of a transposing read land in disjoint banks
+constexpr int TT_SMEM = 2 * (TTK * TTROWA + TTK * TROWB);   // 90 112 B (>= the epilogue's 8 x 9 216 B)
+template <typename TO>
+__global__ __launch_bounds__(512) void gemm_tn_tall_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, TO* __restrict__ C,
+                                                           float* __restrict__ ws, int M, int N, int K, int lda, int ldb, int ldc,
+                                                           int k_per_split, int accumulate, int tiles_n, int tiles_mn, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tt_smem[];
+    constexpr int WBUF = TTK * TTROWA + TTK * TROWB;
+    unsigned char* sA = tt_smem;
+    unsigned char* sB = tt_smem + TTK * TTROWA;
+    const int lin = xcd_remap(blockIdx.x, tiles_mn * nsplit);   // whole K-slices per XCD: the slice's A rows (dh) hit in that L2
+    const int tile = lin % tiles_mn, split = lin / tiles_mn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = (tile / tiles_n) * TTM, n0 = (tile % tiles_n) * BN;
+    const int kbeg = split * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    // staging: A = 32 k rows x 64 chunks of 16 B -> 4 per thread (rows arow + 8 i); B = 32 x 16 chunks -> 1 per thread
+    const int arow = tid >> 6, ach = tid & 63, brow = tid >> 4, bch = tid & 15;
+    typedef tn_u32x4 RegA[4];
+    RegA a0, a1, a2;
+    tn_u32x4 b0, b1, b2;
+    uint32_t aoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoff[i] = (uint32_t)(((size_t)(arow + 8 * i) * lda + ach * 8) * 2);
+    const uint32_t boff = (uint32_t)(((size_t)brow * ldb + bch * 8) * 2);
+    const int nfull = (kend - kbeg) / TTK, krem = (kend - kbeg) % TTK;
+    auto load_full = [&](int t, RegA& ra, tn_u32x4& rb) __attribute__((always_inline)) {
+        const int k0 = kbeg + min(t, nfull - 1) * TTK;   // uniform; a prefetch past the last full tile re-reads it (never consumed)
+        const unsigned char* ab = reinterpret_cast<const unsigned char*>(A + (size_t)k0 * lda + m0);
+        const unsigned char* bb = reinterpret_cast<const unsigned char*>(B + (size_t)k0 * ldb + n0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const tn_u32x4*>(ab + aoff[i]);
+        rb = *reinterpret_cast<const tn_u32x4*>(bb + boff);
+    };
+    auto load_partial = [&](int k0, RegA& ra, tn_u32x4& rb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + arow + 8 * i;
+            ra[i] = k < kend ? *reinterpret_cast<const tn_u32x4*>(A + (size_t)k * lda + m0 + ach * 8) : tn_u32x4{0u, 0u, 0u, 0u};
+        }
+        const int k = k0 + brow;
+        rb = k < kend ? *reinterpret_cast<const tn_u32x4*>(B + (size_t)k * ldb + n0 + bch * 8) : tn_u32x4{0u, 0u, 0u, 0u};
+    };
+    // the five 16-byte LDS stores of a register tile: part ks of 2 (3 + 2 stores) or all of them (ks < 0)
+    auto store_part = [&](int buf, const RegA& ra, const tn_u32x4& rb, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ks < 0 || ks == (i >= 3 ? 1 : 0)) *reinterpret_cast<tn_u32x4*>(sA + buf + (arow + 8 * i) * TTROWA + ach * 16) = ra[i];
+        if (ks < 0 || ks == 1) *reinterpret_cast<tn_u32x4*>(sB + buf + brow * TROWB + bch * 16) = rb;
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+    const unsigned char* fa0 = sA + (8 * (g >> 1) + q) * TTROWA + (16 * (g & 1) + 4 * pp) * 2 + (wm * 128) * 2;
+    const unsigned char* fb0 = sB + (8 * (g >> 1) + q) * TROWB + (16 * (g & 1) + 4 * pp) * 2 + (wn * 64) * 2;
+    using lds_ptr = s16x4 __attribute__((address_space(3)))*;
+    auto fragA = [&](const unsigned char* p) __attribute__((always_inline)) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * TTROWA));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto multiply = [&](int cur, auto store_tag, int nxt, const RegA& ra, const tn_u32x4& rb) __attribute__((always_inline)) {
+        constexpr bool STORE = decltype(store_tag)::value;
+#pragma unroll
+        for (int ks = 0; ks < TTK / 16; ++ks) {
+            bf16x8 a[4], b[2];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) a[f] = fragA(fa0 + cur + ks * 16 * TTROWA + f * 64);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) b[f] = tr_frag(fb0 + cur + ks * 16 * TROWB + f * 64);
+            if constexpr (STORE) store_part(nxt, ra, rb, ks);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    using yes = std::true_type;
+    using no = std::false_type;
+    if (nfull > 0) {
+        load_full(0, a0, b0);
+        load_full(1, a1, b1);
+        load_full(2, a2, b2);
+        store_part(0, a0, b0, -1);
+        load_full(3, a0, b0);
+        __syncthreads();
+        auto step = [&](int t, RegA& ra, tn_u32x4& rb) __attribute__((always_inline)) {   // (ra, rb) hold tile t + 1
+            multiply((t & 1) * WBUF, yes{}, ((t + 1) & 1) * WBUF, ra, rb);
+            load_full(t + 4, ra, rb);
+            __syncthreads();
+        };
+        auto step_noload = [&](int t, const RegA& ra, const tn_u32x4& rb) __attribute__((always_inline)) {
+            multiply((t & 1) * WBUF, yes{}, ((t + 1) & 1) * WBUF, ra, rb);
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + 4 <= nfull; t += 3) {
+            step(t, a1, b1);
+            step(t + 1, a2, b2);
+            step(t + 2, a0, b0);
+        }
+        const int left = nfull - t;   // 1, 2 or 3 tiles: t in buffer t & 1, t + 1 in (a1, b1), t + 2 in (a2, b2)
+        if (left >= 2) {
+            step_noload(t, a1, b1);
+            if (left == 3) step_noload(t + 1, a2, b2);
+        }
+        multiply(((nfull - 1) & 1) * WBUF, no{}, 0, a0, b0);
+        __syncthreads();
+    }
+    if (krem > 0) {
+        load_partial(kbeg + nfull * TTK, a0, b0);
+        store_part(0, a0, b0, -1);
+        __syncthreads();
+        multiply(0, no{}, 0, a0, b0);
+        __syncthreads();
+    }
+    // the wave's 128 x 64 block leaves as two 64 x 64 halves through the shared epilogue
+    store_acc_tile<TO>(&acc[0], tt_smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr, nullptr, 0, 0, wm * 128, wn * 64);
+    store_acc_tile<TO>(&acc[2], tt_smem, nullptr, C, ws, M, N, ldc, accumulate, m0, n0, split, 0, 0, 0, nullptr, nullptr, 0, 0, wm * 128 + 64, wn * 64);
+}
+
 // the batched launch on the 256 x 128 tile: every problem's M a multiple of 256, N of 128 (the encoder layers' 768 x 512 / 512 x 768
 // weight gradients: 12 tiles each).  The batched 128 x 128 kernel moves 2.45 GB through the L2 -> LDS path for the six 33 280-row
 // gradients of a step (144 us at the ~17 TB/s that path sustains chip-wide, against 75 us of MFMA issue); this tile moves 1.84 GB.
@@ -2044,6 +2182,21 @@ static int gemm_tn_impl(const void* A, const void* B, void* C, int M, int N, int
         SPV_COUNT_PATH(SPV_PATH_GEMM_TN_DMA);
     } else
 #endif
+    static const int use_tall = SPV_LAB_INT("SPV_TN_TALL", 1);
+    if (use_tall && M == TTM && N % BN == 0 && N >= 8 * BN && tiles_n * splits >= 192 && k_per_split >= 16 * TTK) {
+        // all of M in one workgroup: the B panel (the gathered matrix of the MHPermutMix gradient) is read once
+        const int nwg = tiles_n * splits;
+        if (out_dtype == SPV_BF16) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tall_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, TT_SMEM);
+            hipLaunchKernelGGL((gemm_tn_tall_kernel<bf16_t>), dim3(nwg), dim3(512), TT_SMEM, st, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, ws, M, N, K, lda, ldb,
+                               ldc, k_per_split, accumulate, tiles_n, tiles_n, splits);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_tall_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, TT_SMEM);
+            hipLaunchKernelGGL((gemm_tn_tall_kernel<float>), dim3(nwg), dim3(512), TT_SMEM, st, (const bf16_t*)A, (const bf16_t*)B, (float*)C, ws, M, N, K, lda, ldb,
+                               ldc, k_per_split, accumulate, tiles_n, tiles_n, splits);
+        }
+        SPV_LAUNCH_CHECK("spv_gemm_tn(tall)");
+    } else
     if (use_wide && splits >= wide_min && M % TWM == 0 && N % BN == 0 && (M / TWM) * tiles_n * splits >= 128) {
         // the 256 x 128 tile (8 waves, one workgroup per CU): the split-K layer weight gradients (SPV_TN_WIDE=0 for the 128 x 128
         // kernel).  Measured in graph mode, alternating: 2.372 vs 2.385 ms/step -- 1.6 us per launch; without split-K (the MHPermutMix

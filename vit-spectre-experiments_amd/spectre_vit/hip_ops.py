@@ -671,6 +671,9 @@ def _weight_grad(dh, x, rows, n, k, sink=None, fold=None, fold_sunk=False):
     splits = max(1, min(512 // tiles, (rows + 511) // 512 if tiles >= 8 else (rows + 63) // 64))
     if tiles < 8:
         splits = min(splits, 64)  # the patch-embedding gradient (512 x 48): 128 slices made the reduce (10 us) as long as the GEMM
+    elif n == 512 and k % 128 == 0 and k >= 1024 and rows >= 8192:
+        # the 512 x 128 tile (spv_gemm_tn takes it from 192 workgroups up): one workgroup per CU
+        splits = max(1, min(256 // (k // 128), rows // 2048))
     # (The 256 x 128 tile at 4 slices is 8 % faster on the MHPermutMix gradient [512, 8192, 33280] in isolation -- 320 against 348 us --
     # and SLOWER where it runs, on the side stream beside the data-gradient GEMM and the inverse gather: 701 against ~500 us, step 5.92
     # -> 6.25 ms.  Its 112 KB of LDS per workgroup leave those kernels less of every CU than the 128 x 128 tile's 40 KB.)
